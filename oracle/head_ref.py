@@ -1,0 +1,146 @@
+"""Plain-PyTorch restatement of the DeepLabv3+ head (test infrastructure).
+
+Follows the reference graph:
+  ASPP branch      /root/reference/newmodeling/aspp.py:7-21   (conv -> BN -> ReLU)
+  ASPP             /root/reference/newmodeling/aspp.py:34-81  (rates :44-49, pooling branch :56-59,
+                   align-corners broadcast :72, concat :75, 1x1 projection + BN + ReLU + Dropout(.5) :77-81)
+  Decoder          /root/reference/newmodeling/decoder.py:8-52 (1x1 -> 48ch :22-24, upsample :48,
+                   concat :49, two 3x3 + BN + ReLU + Dropout(.5/.1) and biased classifier :27-38)
+  DeepLab wiring   /root/reference/newmodeling/deeplab.py:29-35
+  init             kaiming_normal on convs, BN gamma=1 beta=0 (aspp.py:83-94, decoder.py:55-64)
+Attribute names equal the reference's so a reference state_dict loads unchanged.
+"""
+import importlib.util
+import os
+import sys
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_ASPP_INPLANES = {"drn": 512, "mobilenet": 320, "ghostnet": 160}
+_ASPP_RATES = {16: (1, 6, 12, 18), 8: (1, 12, 24, 36)}
+_LOW_LEVEL = {"resnet": 256, "drn": 256, "xception": 128, "mobilenet": 24, "ghostnet": 24}
+
+
+def _reset(module):
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight)
+        elif isinstance(m, nn.modules.batchnorm._BatchNorm):
+            m.weight.data.fill_(1)
+            m.bias.data.zero_()
+
+
+def _up(x, size):
+    return F.interpolate(x, size=size, mode="bilinear", align_corners=True)
+
+
+class RefBranch(nn.Module):
+    def __init__(self, inplanes, planes, kernel_size, padding, dilation, BatchNorm):
+        super().__init__()
+        self.atrous_conv = nn.Conv2d(inplanes, planes, kernel_size, 1, padding, dilation, bias=False)
+        self.bn = BatchNorm(planes)
+        _reset(self)
+
+    def forward(self, x):
+        return F.relu(self.bn(self.atrous_conv(x)))
+
+
+class RefASPP(nn.Module):
+    def __init__(self, backbone, output_stride, BatchNorm, inplanes=None, planes=256, ghostnet_160=False):
+        super().__init__()
+        if inplanes is None:
+            inplanes = _ASPP_INPLANES.get(backbone, 2048)
+            if backbone == "ghostnet" and not ghostnet_160:
+                inplanes = 2048  # newmodeling/aspp.py has no ghostnet case; modeling/aspp.py:41 has (160)
+        if output_stride not in _ASPP_RATES:
+            raise NotImplementedError
+        r = _ASPP_RATES[output_stride]
+        self.aspp1 = RefBranch(inplanes, planes, 1, 0, r[0], BatchNorm)
+        self.aspp2 = RefBranch(inplanes, planes, 3, r[1], r[1], BatchNorm)
+        self.aspp3 = RefBranch(inplanes, planes, 3, r[2], r[2], BatchNorm)
+        self.aspp4 = RefBranch(inplanes, planes, 3, r[3], r[3], BatchNorm)
+        self.global_avg_pool = nn.Sequential(
+            nn.AdaptiveAvgPool2d((1, 1)), nn.Conv2d(inplanes, planes, 1, bias=False), BatchNorm(planes), nn.ReLU())
+        self.conv1 = nn.Conv2d(5 * planes, planes, 1, bias=False)
+        self.bn1 = BatchNorm(planes)
+        self.dropout = nn.Dropout(0.5)
+        _reset(self)
+
+    def forward(self, x):
+        size = x.shape[2:]
+        parts = [self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x), _up(self.global_avg_pool(x), size)]
+        y = F.relu(self.bn1(self.conv1(torch.cat(parts, dim=1))))
+        return self.dropout(y)
+
+
+class RefDecoder(nn.Module):
+    def __init__(self, num_classes, backbone, BatchNorm, low_level_inplanes=None, planes=256, aspp_planes=256):
+        super().__init__()
+        if low_level_inplanes is None:
+            if backbone not in _LOW_LEVEL:
+                raise NotImplementedError
+            low_level_inplanes = _LOW_LEVEL[backbone]
+        self.conv1 = nn.Conv2d(low_level_inplanes, 48, 1, bias=False)
+        self.bn1 = BatchNorm(48)
+        self.last_conv = nn.Sequential(
+            nn.Conv2d(aspp_planes + 48, planes, 3, 1, 1, bias=False), BatchNorm(planes), nn.ReLU(), nn.Dropout(0.5),
+            nn.Conv2d(planes, planes, 3, 1, 1, bias=False), BatchNorm(planes), nn.ReLU(), nn.Dropout(0.1),
+            nn.Conv2d(planes, num_classes, 1))
+        _reset(self)
+
+    def forward(self, x, low_level_feat):
+        low = F.relu(self.bn1(self.conv1(low_level_feat)))
+        return self.last_conv(torch.cat((_up(x, low.shape[2:]), low), dim=1))
+
+
+def _load_feeder_module():
+    """The feeder is ordinary PyTorch code shipped with the package; load it by path so the
+    oracle does not import the accelerated package."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(here, "..", "semantic-segmentation_amd", "segk", "modeling", "backbone", "resnet.py")
+    name = "_oracle_feeder_resnet"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class RefDeepLab(nn.Module):
+    def __init__(self, backbone="resnet", output_stride=16, num_classes=21, BatchNorm=nn.BatchNorm2d,
+                 feeder="resnet101"):
+        super().__init__()
+        fm = _load_feeder_module()
+        ctor = fm.ResNet101 if feeder == "resnet101" else fm.ResNet50
+        self.backbone = ctor(output_stride, BatchNorm, pretrained=False)
+        self.aspp = RefASPP(backbone, output_stride, BatchNorm)
+        self.decoder = RefDecoder(num_classes, backbone, BatchNorm)
+
+    def forward(self, input):
+        x, low = self.backbone(input)
+        x = self.decoder(self.aspp(x), low)
+        return _up(x, input.shape[2:])
+
+    def lr_groups(self):
+        """(1x params, 10x params) as get_1x_lr_params / get_10x_lr_params yield them
+        (/root/reference/newmodeling/deeplab.py:44-74, freeze_bn False)."""
+        def pick(mods):
+            for root in mods:
+                for m in root.modules():
+                    if isinstance(m, (nn.Conv2d, nn.modules.batchnorm._BatchNorm)):
+                        for p in m.parameters(recurse=False):
+                            if p.requires_grad:
+                                yield p
+        return list(pick([self.backbone])), list(pick([self.aspp, self.decoder]))
+
+
+def set_dropout(module, p=None, enabled=True):
+    """Force every nn.Dropout to probability p (or leave), used to make goldens RNG-free."""
+    for m in module.modules():
+        if isinstance(m, nn.Dropout) and p is not None:
+            m.p = p
+    return module

@@ -1,0 +1,111 @@
+"""ResNet-50/101 feeder with DeepLab output strides (plain PyTorch, not accelerated).
+
+The feeder is outside the accelerated path: it runs as ordinary PyTorch-ROCm
+modules and only hands (x, low_level_feat) to the head.  Its normalisation class
+is injected (``BatchNorm`` argument) exactly as in the reference, so passing
+``SynchronizedBatchNorm2d`` makes all 104 feeder norms use the HIP SyncBN.
+
+Behaviour follows /root/reference/newmodeling/backbone/resnet101_2.py:7-156
+(bottleneck :31-51, strides/dilations per output stride :61-68, multi-grid
+layer4 with rates (1,2,4)·dilation :124-143, forward returning layer4 and
+layer1 features :145-156, init N(0, sqrt(2/(k·k·out))) :220-230).  Attribute
+names are kept so state_dict keys interchange with reference checkpoints.
+There is no network in this environment: ``pretrained=True`` is refused.
+"""
+import math
+
+import torch.nn as nn
+
+_MULTI_GRID = (1, 2, 4)
+
+
+def _conv(cin, cout, k, stride=1, dilation=1):
+    pad = dilation if k == 3 else (3 if k == 7 else 0)
+    return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=pad, dilation=dilation, bias=False)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, BatchNorm=None):
+        super().__init__()
+        self.conv1 = _conv(inplanes, planes, 1)
+        self.bn1 = BatchNorm(planes)
+        self.conv2 = _conv(planes, planes, 3, stride=stride, dilation=dilation)
+        self.bn2 = BatchNorm(planes)
+        self.conv3 = _conv(planes, planes * self.expansion, 1)
+        self.bn3 = BatchNorm(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+        self.dilation = dilation
+
+    def forward(self, x):
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        # the projection runs after the main path: autograd then sums the gradients that
+        # reach x in the same order as the reference does, which keeps training bit-identical
+        y += x if self.downsample is None else self.downsample(x)
+        return self.relu(y)
+
+
+class ResNet(nn.Module):
+    def __init__(self, block, layers, output_stride, BatchNorm, pretrained=False):
+        super().__init__()
+        if pretrained:
+            raise RuntimeError("pretrained feeder weights need a download; load a checkpoint explicitly instead")
+        if output_stride == 16:
+            strides, dilations = (1, 2, 2, 1), (1, 1, 1, 2)
+        elif output_stride == 8:
+            strides, dilations = (1, 2, 1, 1), (1, 1, 2, 4)
+        else:
+            raise NotImplementedError
+        self.inplanes = 64
+        self.conv1 = _conv(3, 64, 7, stride=2)
+        self.bn1 = BatchNorm(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        widths = (64, 128, 256)
+        for i, w in enumerate(widths):
+            rates = [dilations[i]] * layers[i]
+            setattr(self, "layer%d" % (i + 1), self._stage(block, w, rates, strides[i], BatchNorm))
+        rates = [g * dilations[3] for g in _MULTI_GRID]
+        self.layer4 = self._stage(block, 512, rates, strides[3], BatchNorm)
+        self._init_weight()
+
+    def _stage(self, block, planes, rates, stride, BatchNorm):
+        out_ch = planes * block.expansion
+        proj = None
+        if stride != 1 or self.inplanes != out_ch:
+            proj = nn.Sequential(
+                nn.Conv2d(self.inplanes, out_ch, kernel_size=1, stride=stride, bias=False),
+                BatchNorm(out_ch))
+        blocks = [block(self.inplanes, planes, stride, rates[0], proj, BatchNorm)]
+        self.inplanes = out_ch
+        for r in rates[1:]:
+            blocks.append(block(self.inplanes, planes, 1, r, None, BatchNorm))
+        return nn.Sequential(*blocks)
+
+    def forward(self, input):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(input))))
+        low_level_feat = self.layer1(x)
+        x = self.layer4(self.layer3(self.layer2(low_level_feat)))
+        return x, low_level_feat
+
+    def _init_weight(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                fan = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2.0 / fan))
+            elif isinstance(m, nn.modules.batchnorm._BatchNorm):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+
+def ResNet101(output_stride, BatchNorm, pretrained=False):
+    return ResNet(Bottleneck, [3, 4, 23, 3], output_stride, BatchNorm, pretrained=pretrained)
+
+
+def ResNet50(output_stride, BatchNorm, pretrained=False):
+    return ResNet(Bottleneck, [3, 4, 6, 3], output_stride, BatchNorm, pretrained=pretrained)
