@@ -1,0 +1,203 @@
+/*
+ * segk.h — C ABI of libsegk.so: MI355X (gfx950) kernels for the DeepLabv3+ segmentation-head
+ * training step (ASPP, decoder, synchronized batch norm, cross-entropy, confusion matrix).
+ *
+ * Conventions
+ *   - Every entry point returns SEGK_OK (0) or a negative segk_status; segk_last_error() gives the
+ *     message of the calling thread's last failure.  No C++ exception crosses this boundary.
+ *   - All pointers are DEVICE pointers borrowed from the caller (e.g. torch's allocator) unless a
+ *     parameter is documented as host.  The library allocates no device memory and keeps no pointer
+ *     after a call returns.  Kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL =
+ *     the default stream) and the call returns without synchronising.
+ *   - Activations inside the head are "pixel-major": a [M][ld] matrix with M = N*H*W pixels, the
+ *     channels of one pixel contiguous, `ld` >= channel count (elements) so that a tensor may be a
+ *     channel slice of a wider concat buffer.  dtype is SEGK_F32 or SEGK_BF16.
+ *   - Contracted channel counts of the convolution entry points must be multiples of 32; callers pad
+ *     buffers with zero channels (weights are padded by segk_pack_weight).
+ *
+ * Each declaration cites the reference code (paths relative to the reference tree) that it replaces.
+ */
+#ifndef SEGK_H
+#define SEGK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  SEGK_OK = 0,
+  SEGK_INVALID_ARG = -1,
+  SEGK_UNSUPPORTED_SHAPE = -2,
+  SEGK_WORKSPACE_TOO_SMALL = -3,
+  SEGK_HIP_ERROR = -4
+} segk_status;
+
+typedef enum { SEGK_F32 = 0, SEGK_BF16 = 1 } segk_dtype;
+
+typedef void* segk_stream_t; /* hipStream_t */
+
+#define SEGK_MAX_SEG 4
+
+/* ---- library ------------------------------------------------------------------------------- */
+int segk_version(void);
+const char* segk_last_error(void);
+/* Number of visible HIP devices, or a negative status; touches no device memory. */
+int segk_device_count(void);
+
+/* ---- layout changes at the boundary --------------------------------------------------------- */
+/* NCHW fp32 (the feeder's tensors, modeling/deeplab.py:249-250) -> pixel-major [N*H*W][dst_ld]. */
+int segk_nchw_to_pm(const float* src, void* dst, int dst_dtype, int N, int C, int H, int W, int dst_ld,
+                    segk_stream_t stream);
+/* pixel-major -> NCHW fp32 (gradients handed back to the feeder's autograd). */
+int segk_pm_to_nchw(const void* src, int src_dtype, int src_ld, float* dst, int N, int C, int H, int W,
+                    segk_stream_t stream);
+
+/* ---- convolution as implicit GEMM ----------------------------------------------------------- */
+/* nn.Conv2d weights [Cout][Cin][R][R] fp32 (modeling/aspp.py:10-11, modeling/decoder.py:132,142-153)
+ * -> operand layout of segk_conv_fwd.
+ *   transpose = 0: dst[tap][rows = Cout][Ck = Cin rounded up to 32]           (forward)
+ *   transpose = 1: dst[R*R-1-tap][rows = Cin][Ck = Cout rounded up to 32]     (data gradient)
+ * Padding columns are written as zeros. */
+int segk_pack_weight(const float* w_oihw, void* dst, int dst_dtype, int Cout, int Cin, int R, int transpose,
+                     segk_stream_t stream);
+
+typedef struct {
+  const void* in;  /* [M][in_ld] activations, args.dtype */
+  const void* w;   /* packed weights [R*R][rows = Cout][Ck], args.dtype */
+  int in_ld;
+  int Ck;          /* contracted channels, multiple of 32, <= in_ld */
+  int R;           /* 1 or 3 (square kernel, stride 1, padding = dil*(R-1)/2: output size = input size) */
+  int dil;
+} segk_conv_seg;
+
+typedef struct {
+  int N, H, W;
+  int dtype;        /* of in / w */
+  int Cout;         /* output channels (rows of every segment's packed weight) */
+  int nseg;         /* 1..SEGK_MAX_SEG; the segments' products are summed into one output */
+  segk_conv_seg seg[SEGK_MAX_SEG];
+  void* out;        /* [M][out_ld] */
+  int out_ld;
+  int out_dtype;
+  const float* bias;      /* [Cout] or NULL (modeling/decoder.py:152-153, classifier) */
+  const float* img_bias;  /* [N][Cout] or NULL: added to every pixel of image n */
+  float* stat_partials;   /* NULL, or [segk_conv_stat_rows(&a)][2][Cout] fp32: per-row-tile sum and
+                             sum of squares of the UNBIASED output, for batch-norm statistics */
+} segk_conv_args;
+
+/* nn.Conv2d forward (modeling/aspp.py:18, modeling/decoder.py:172,178) and, with transposed packed
+ * weights, its data gradient.  out[m][co] = sum_seg sum_tap sum_c in[m + tap][c] * w[tap][co][c]. */
+int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream);
+/* Number of partial rows segk_conv_fwd writes to stat_partials for this problem. */
+int segk_conv_stat_rows(const segk_conv_args* a);
+
+typedef struct {
+  int N, H, W;
+  int dtype;       /* of in / dout */
+  const void* in;  /* [M][in_ld] forward input */
+  int in_ld;
+  int Cin;         /* multiple of 32 (padded channels included) */
+  const void* dout;/* [M][dout_ld] gradient w.r.t. the conv output */
+  int dout_ld;
+  int Cout;        /* multiple of 16 */
+  int R, dil;
+  int splits;      /* >= 1: the pixel range is cut into `splits` parts summed later in fixed order */
+  float* slabs;    /* [splits][R*R][Cin][Cout] fp32 partial weight gradients */
+} segk_wgrad_args;
+
+/* Weight gradient of nn.Conv2d (autograd of modeling/aspp.py:18, modeling/decoder.py:172,178). */
+int segk_conv_wgrad(const segk_wgrad_args* a, segk_stream_t stream);
+/* Sum the split slabs in index order and write nn.Conv2d layout:
+ * dw[co][ci][r][s] = sum_split slabs[split][tap][ci][co], co < Cout_true, ci < Cin_true. */
+int segk_wgrad_finish(const float* slabs, int splits, int R, int Cin, int Cout, float* dw_oihw, int Cout_true,
+                      int Cin_true, segk_stream_t stream);
+
+/* ---- batch normalisation (synchronized) ----------------------------------------------------- */
+/* Layouts for the BN entry points. */
+typedef enum { SEGK_PM = 0 /* [M][ld], channels contiguous */, SEGK_NCHW = 1 /* [N][C][HW] */ } segk_layout;
+
+/* Per-channel sum and sum of squares (modeling/sync_batchnorm/batchnorm.py:60-62).
+ * partials: [segk_bn_stat_rows(...)][2][C] fp32. */
+int segk_bn_stats(const void* x, int dtype, int layout, int N, int C, int HW, int ld, float* partials,
+                  segk_stream_t stream);
+int segk_bn_stat_rows(int layout, int N, int C, int HW);
+/* Sum `rows` partial rows in index order: sums[0..C) = sum x, sums[C..2C) = sum x^2, sums[2C] = count.
+ * The [2C+1] vector is what ranks all-reduce (replaces ReduceAddCoalesced, batchnorm.py:101-102). */
+int segk_bn_reduce(const float* partials, int rows, int C, float count, float* sums, segk_stream_t stream);
+/* Global sums -> mean, inv_std, running statistics and the affine coefficients
+ * scale = gamma*inv_std, shift = beta - mean*scale (batchnorm.py:113-125 and :73).
+ * legacy_clamp != 0: inv_std = clamp(var, eps)^-1/2 (batchnorm.py:125); 0: (var + eps)^-1/2 (F.batch_norm,
+ * batchnorm.py:50-53).  running_* may be NULL.  gamma/beta NULL = 1/0. */
+int segk_bn_coeffs(const float* sums, const float* gamma, const float* beta, float eps, float momentum,
+                   int legacy_clamp, float* running_mean, float* running_var, float* mean, float* inv_std,
+                   float* scale, float* shift, int C, segk_stream_t stream);
+/* Evaluation mode (batchnorm.py:50-53 with training False): coefficients from running statistics. */
+int segk_bn_coeffs_eval(const float* running_mean, const float* running_var, const float* gamma,
+                        const float* beta, float eps, float* mean, float* inv_std, float* scale, float* shift,
+                        int C, segk_stream_t stream);
+/* y = x*scale + shift, optional ReLU, optional dropout mask (mask[m][c] in {0,1} bytes, laid out like y
+ * with leading dimension C; the kept values are multiplied by mask_scale = 1/(1-p)).
+ * (batchnorm.py:73, modeling/aspp.py:21,147, modeling/decoder.py:145-151) */
+int segk_bn_apply(const void* x, int x_dtype, int x_ld, void* y, int y_dtype, int y_ld, int layout, int N, int C,
+                  int HW, const float* scale, const float* shift, int relu, const uint8_t* mask,
+                  float mask_scale, segk_stream_t stream);
+/* Backward, pass 1: with g = dz * mask * [relu active], per-channel partial sums of g and g*xhat.
+ * partials: [segk_bn_stat_rows(...)][2][C]. */
+int segk_bn_bwd_stats(const void* dz, int dz_dtype, int dz_ld, const void* x, int x_dtype, int x_ld, int layout,
+                      int N, int C, int HW, const float* mean, const float* inv_std, const float* scale,
+                      const float* shift, int relu, const uint8_t* mask, float mask_scale, float* partials,
+                      segk_stream_t stream);
+/* Backward, pass 2: dx = scale * (g - sum_g/count - xhat * sum_gxhat/count) with the GLOBAL sums
+ * gsums = [sum g (C), sum g*xhat (C), count] (autograd of batchnorm.py:66-73 through the reduction);
+ * eval != 0: dx = scale * g.  */
+int segk_bn_bwd_apply(const void* dz, int dz_dtype, int dz_ld, const void* x, int x_dtype, int x_ld, void* dx,
+                      int dx_dtype, int dx_ld, int layout, int N, int C, int HW, const float* mean,
+                      const float* inv_std, const float* scale, const float* shift, int relu,
+                      const uint8_t* mask, float mask_scale, const float* gsums, int eval,
+                      segk_stream_t stream);
+
+/* ---- pooling / resampling ------------------------------------------------------------------- */
+/* nn.AdaptiveAvgPool2d((1,1)) on a pixel-major tensor (modeling/aspp.py:121): out[n][c] fp32 =
+ * scale * sum_pixels x[n][p][c]  (scale = 1/HW forward; 1 to sum a gradient). */
+int segk_pool_sum(const void* x, int dtype, int ld, int N, int HW, int C, float scale, float* out,
+                  segk_stream_t stream);
+/* F.interpolate(mode='bilinear', align_corners=True) (modeling/aspp.py:137, modeling/decoder.py:176,
+ * modeling/deeplab.py:252).  Source is pixel-major [N*Hi*Wi][in_ld]; the destination is pixel-major
+ * (out_layout = SEGK_PM, [N*Ho*Wo][out_ld], out_dtype) or NCHW fp32 (out_layout = SEGK_NCHW). */
+int segk_upsample_fwd(const void* in, int in_dtype, int in_ld, int N, int C, int Hi, int Wi, void* out,
+                      int out_dtype, int out_layout, int out_ld, int Ho, int Wo, segk_stream_t stream);
+/* Its gradient, gather form (no atomics): din[n][iy][ix][c] = sum over the output pixels that read it.
+ * dout is pixel-major or NCHW fp32 as above; din is pixel-major [N*Hi*Wi][din_ld]; channels
+ * C..din_cpad of din are written as zero. */
+int segk_upsample_bwd(const void* dout, int dout_dtype, int dout_layout, int dout_ld, int N, int C, int Ho,
+                      int Wo, void* din, int din_dtype, int din_ld, int din_cpad, int Hi, int Wi,
+                      segk_stream_t stream);
+
+/* ---- loss ----------------------------------------------------------------------------------- */
+/* nn.CrossEntropyLoss(weight, ignore_index) on NCHW fp32 logits and fp32 label maps (utils/loss.py:23-35).
+ * Writes lse[N*H*W] (log-sum-exp per pixel) and sums[2] = {sum w*nll, sum w} over non-ignored pixels
+ * (fp32, reduced in fixed order through `partials`, which must hold segk_ce_partial_rows(P)*2 floats). */
+int segk_ce_fwd(const float* logits, const float* target, const float* weight, int N, int K, int HW,
+                int ignore_index, float* lse, float* partials, float* sums, segk_stream_t stream);
+int segk_ce_partial_rows(long long pixels);
+/* dlogits[n][k][p] = coef * w_t * (softmax_k - [k == t]) for non-ignored pixels, 0 otherwise, where
+ * coef = *coef_dev (device scalar: grad_out / (sum w * batch)). */
+int segk_ce_bwd(const float* logits, const float* target, const float* weight, const float* lse, int N, int K,
+                int HW, int ignore_index, const float* coef_dev, float* dlogits, segk_stream_t stream);
+
+/* ---- evaluator ------------------------------------------------------------------------------ */
+/* np.argmax(logits, axis=1) (train.py:217): first maximal index, NaN counts as maximal. */
+int segk_argmax(const float* logits, int N, int K, int HW, int64_t* pred, segk_stream_t stream);
+/* Evaluator._generate_matrix + add_batch (utils/metrics.py:44-54): for pixels with 0 <= gt < K,
+ * cm[K*int(gt) + pred] += 1.  cm is int64 [K*K + 1]; the extra slot counts pixels whose prediction lies
+ * outside [0,K) (np.bincount would fail on those).  gt is fp32 (gt_is_i64 = 0) or int64. */
+int segk_confmat(const void* gt, int gt_is_i64, const int64_t* pred, long long count, int K, int64_t* cm,
+                 segk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEGK_H */

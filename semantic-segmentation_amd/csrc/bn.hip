@@ -1,0 +1,629 @@
+// Batch-normalisation kernels (training with global statistics, evaluation, and their gradients).
+// All HBM-bound.  Two layouts: pixel-major [M][ld] (head internals) and NCHW (the feeder's tensors).
+// Statistics are produced as per-block partial rows that a second kernel sums in index order, so the
+// result does not depend on scheduling (no float atomics).
+#include "common.h"
+
+namespace segk {
+
+constexpr int BN_THREADS = 256;
+constexpr int BN_MAX_ROWS_PM = 1024;
+constexpr int BN_MAX_ROWS_NCHW = 32;
+
+template <typename T, int VEC>
+__device__ __forceinline__ void load_vec(const T* p, float (&v)[VEC]);
+template <>
+__device__ __forceinline__ void load_vec<float, 4>(const float* p, float (&v)[4]) {
+  f32x4 t = *reinterpret_cast<const f32x4*>(p);
+  v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+template <>
+__device__ __forceinline__ void load_vec<float, 1>(const float* p, float (&v)[1]) { v[0] = *p; }
+template <>
+__device__ __forceinline__ void load_vec<bf16_t, 4>(const bf16_t* p, float (&v)[4]) {
+  u32x2 t = *reinterpret_cast<const u32x2*>(p);
+  v[0] = __uint_as_float(t[0] << 16); v[1] = __uint_as_float(t[0] & 0xffff0000u);
+  v[2] = __uint_as_float(t[1] << 16); v[3] = __uint_as_float(t[1] & 0xffff0000u);
+}
+template <>
+__device__ __forceinline__ void load_vec<bf16_t, 1>(const bf16_t* p, float (&v)[1]) { v[0] = bf16_to_f32(*p); }
+
+template <typename T, int VEC>
+__device__ __forceinline__ void store_vec(T* p, const float (&v)[VEC]);
+template <>
+__device__ __forceinline__ void store_vec<float, 4>(float* p, const float (&v)[4]) {
+  f32x4 t = {v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(p) = t;
+}
+template <>
+__device__ __forceinline__ void store_vec<float, 1>(float* p, const float (&v)[1]) { *p = v[0]; }
+template <>
+__device__ __forceinline__ void store_vec<bf16_t, 4>(bf16_t* p, const float (&v)[4]) {
+  u32x2 t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+  *reinterpret_cast<u32x2*>(p) = t;
+}
+template <>
+__device__ __forceinline__ void store_vec<bf16_t, 1>(bf16_t* p, const float (&v)[1]) { *p = f32_to_bf16(v[0]); }
+
+template <int VEC>
+__device__ __forceinline__ void load_mask(const uint8_t* p, float (&v)[VEC]);
+template <>
+__device__ __forceinline__ void load_mask<4>(const uint8_t* p, float (&v)[4]) {
+  unsigned int t = *reinterpret_cast<const unsigned int*>(p);
+  v[0] = (float)(t & 0xff); v[1] = (float)((t >> 8) & 0xff); v[2] = (float)((t >> 16) & 0xff); v[3] = (float)(t >> 24);
+}
+template <>
+__device__ __forceinline__ void load_mask<1>(const uint8_t* p, float (&v)[1]) { v[0] = (float)*p; }
+
+// ---------------------------------------------------------------------------------------------
+// Pixel-major kernels.  Thread t owns channel group (t % cg) and walks pixels (t / cg) + k*rpb.
+// ---------------------------------------------------------------------------------------------
+struct PmGeom {
+  int cg;   // channel groups = C / VEC
+  int rpb;  // pixel rows handled per block iteration = BN_THREADS / cg (>= 1)
+};
+
+// Combine the per-thread accumulators a[VEC], b[VEC] of all pixel rows of the block and write one partial row.
+template <int VEC>
+__device__ __forceinline__ void block_reduce_pm(float (&a)[VEC], float (&b)[VEC], int C, PmGeom g, float* out_row) {
+  __shared__ float red[2 * BN_THREADS * 4];
+  const int cgi = threadIdx.x % g.cg, pr = threadIdx.x / g.cg;
+  const bool active = pr < g.rpb;
+  // layout red[pr][2][C]
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      red[(pr * 2 + 0) * C + cgi * VEC + j] = a[j];
+      red[(pr * 2 + 1) * C + cgi * VEC + j] = b[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += BN_THREADS) {
+    float s = 0.f;
+    for (int r = 0; r < g.rpb; ++r) s += red[r * 2 * C + i];
+    out_row[i] = s;
+  }
+}
+
+template <typename TX, int VEC>
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_pm_kernel(const TX* __restrict__ x, int ld, long long M, int C,
+                                                                  PmGeom g, float* __restrict__ partials) {
+  const int cgi = threadIdx.x % g.cg, pr = threadIdx.x / g.cg;
+  float a[VEC], b[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) a[j] = b[j] = 0.f;
+  const long long per = (M + gridDim.x - 1) / gridDim.x;
+  const long long m0 = (long long)blockIdx.x * per;
+  const long long m1 = m0 + per < M ? m0 + per : M;
+  if (pr < g.rpb) {
+    for (long long m = m0 + pr; m < m1; m += g.rpb) {
+      float v[VEC];
+      load_vec<TX, VEC>(x + m * ld + cgi * VEC, v);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        a[j] += v[j];
+        b[j] = fmaf(v[j], v[j], b[j]);
+      }
+    }
+  }
+  block_reduce_pm<VEC>(a, b, C, g, partials + (size_t)blockIdx.x * 2 * C);
+}
+
+// g = dz * mask * mask_scale * [x*scale+shift > 0]
+template <int VEC>
+__device__ __forceinline__ void grad_through_act(float (&gz)[VEC], const float (&xv)[VEC], const float* sc,
+                                                 const float* sh, int relu, const uint8_t* mask_p, float mask_scale) {
+  if (mask_p) {
+    float mk[VEC];
+    load_mask<VEC>(mask_p, mk);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) gz[j] *= mk[j] * mask_scale;
+  }
+  if (relu) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+      if (!(fmaf(xv[j], sc[j], sh[j]) > 0.f)) gz[j] = 0.f;
+  }
+}
+
+template <typename TG, typename TX, int VEC>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_pm_kernel(
+    const TG* __restrict__ dz, int dz_ld, const TX* __restrict__ x, int x_ld, long long M, int C, PmGeom g,
+    const float* __restrict__ mean, const float* __restrict__ inv_std, const float* __restrict__ scale,
+    const float* __restrict__ shift, int relu, const uint8_t* __restrict__ mask, float mask_scale,
+    float* __restrict__ partials) {
+  const int cgi = threadIdx.x % g.cg, pr = threadIdx.x / g.cg;
+  float a[VEC], b[VEC], mu[VEC], is[VEC], sc[VEC], sh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    a[j] = b[j] = 0.f;
+    const int c = (cgi * VEC + j) % C;
+    mu[j] = mean[c]; is[j] = inv_std[c]; sc[j] = scale[c]; sh[j] = shift[c];
+  }
+  const long long per = (M + gridDim.x - 1) / gridDim.x;
+  const long long m0 = (long long)blockIdx.x * per;
+  const long long m1 = m0 + per < M ? m0 + per : M;
+  if (pr < g.rpb) {
+    for (long long m = m0 + pr; m < m1; m += g.rpb) {
+      float gz[VEC], xv[VEC];
+      load_vec<TG, VEC>(dz + m * dz_ld + cgi * VEC, gz);
+      load_vec<TX, VEC>(x + m * x_ld + cgi * VEC, xv);
+      grad_through_act<VEC>(gz, xv, sc, sh, relu, mask ? mask + m * C + cgi * VEC : nullptr, mask_scale);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        a[j] += gz[j];
+        b[j] = fmaf(gz[j], (xv[j] - mu[j]) * is[j], b[j]);
+      }
+    }
+  }
+  block_reduce_pm<VEC>(a, b, C, g, partials + (size_t)blockIdx.x * 2 * C);
+}
+
+template <typename TX, typename TY, int VEC>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_pm_kernel(const TX* __restrict__ x, int x_ld, TY* __restrict__ y,
+                                                                  int y_ld, long long M, int C, int cg,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, int relu,
+                                                                  const uint8_t* __restrict__ mask, float mask_scale) {
+  const long long total = M * cg;
+  for (long long i = (long long)blockIdx.x * BN_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * BN_THREADS) {
+    const long long m = i / cg;
+    const int c0 = (int)(i - m * cg) * VEC;
+    float v[VEC], o[VEC];
+    load_vec<TX, VEC>(x + m * x_ld + c0, v);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float t = fmaf(v[j], scale[c0 + j], shift[c0 + j]);
+      if (relu) t = t > 0.f ? t : 0.f;
+      o[j] = t;
+    }
+    if (mask) {
+      float mk[VEC];
+      load_mask<VEC>(mask + m * C + c0, mk);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] *= mk[j] * mask_scale;
+    }
+    store_vec<TY, VEC>(y + m * y_ld + c0, o);
+  }
+}
+
+template <typename TG, typename TX, int VEC>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_pm_kernel(
+    const TG* __restrict__ dz, int dz_ld, const TX* __restrict__ x, int x_ld, TG* __restrict__ dx, int dx_ld,
+    long long M, int C, int cg, const float* __restrict__ mean, const float* __restrict__ inv_std,
+    const float* __restrict__ scale, const float* __restrict__ shift, int relu, const uint8_t* __restrict__ mask,
+    float mask_scale, const float* __restrict__ gsums, int eval) {
+  const long long total = M * cg;
+  const float inv_count = eval ? 0.f : 1.f / gsums[2 * C];
+  for (long long i = (long long)blockIdx.x * BN_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * BN_THREADS) {
+    const long long m = i / cg;
+    const int c0 = (int)(i - m * cg) * VEC;
+    float gz[VEC], xv[VEC], o[VEC], sc[VEC], sh[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
+    load_vec<TG, VEC>(dz + m * dz_ld + c0, gz);
+    load_vec<TX, VEC>(x + m * x_ld + c0, xv);
+    grad_through_act<VEC>(gz, xv, sc, sh, relu, mask ? mask + m * C + c0 : nullptr, mask_scale);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = c0 + j;
+      if (eval) {
+        o[j] = sc[j] * gz[j];
+      } else {
+        const float xh = (xv[j] - mean[c]) * inv_std[c];
+        o[j] = sc[j] * (gz[j] - gsums[c] * inv_count - xh * (gsums[C + c] * inv_count));
+      }
+    }
+    store_vec<TG, VEC>(dx + m * dx_ld + c0, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NCHW kernels: block (c, s) reduces pixel slice s of channel c over all images.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_reduce2(float& a, float& b) {
+  __shared__ float ra[BN_THREADS / 64], rb[BN_THREADS / 64];
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { ra[w] = a; rb[w] = b; }
+  __syncthreads();
+  a = ra[0] + ra[1] + ra[2] + ra[3];
+  b = rb[0] + rb[1] + rb[2] + rb[3];
+}
+
+template <typename TX>
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_nchw_kernel(const TX* __restrict__ x, int N, int C, int HW,
+                                                                    float* __restrict__ partials) {
+  const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+  const int per = (HW + S - 1) / S;
+  const int p0 = s * per, p1 = min(HW, p0 + per);
+  float a = 0.f, b = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const TX* row = x + ((size_t)n * C + c) * HW;
+    for (int p = p0 + threadIdx.x; p < p1; p += BN_THREADS) {
+      float v = Elem<TX>::load(row + p);
+      a += v;
+      b = fmaf(v, v, b);
+    }
+  }
+  block_reduce2(a, b);
+  if (threadIdx.x == 0) {
+    partials[((size_t)s * 2 + 0) * C + c] = a;
+    partials[((size_t)s * 2 + 1) * C + c] = b;
+  }
+}
+
+template <typename TG, typename TX>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_nchw_kernel(
+    const TG* __restrict__ dz, const TX* __restrict__ x, int N, int C, int HW, const float* __restrict__ mean,
+    const float* __restrict__ inv_std, const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+    const uint8_t* __restrict__ mask, float mask_scale, float* __restrict__ partials) {
+  const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+  const int per = (HW + S - 1) / S;
+  const int p0 = s * per, p1 = min(HW, p0 + per);
+  const float mu = mean[c], is = inv_std[c], sc = scale[c], sh = shift[c];
+  float a = 0.f, b = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const size_t base = ((size_t)n * C + c) * HW;
+    for (int p = p0 + threadIdx.x; p < p1; p += BN_THREADS) {
+      float g = Elem<TG>::load(dz + base + p);
+      const float v = Elem<TX>::load(x + base + p);
+      if (mask) g *= (float)mask[base + p] * mask_scale;
+      if (relu && !(fmaf(v, sc, sh) > 0.f)) g = 0.f;
+      a += g;
+      b = fmaf(g, (v - mu) * is, b);
+    }
+  }
+  block_reduce2(a, b);
+  if (threadIdx.x == 0) {
+    partials[((size_t)s * 2 + 0) * C + c] = a;
+    partials[((size_t)s * 2 + 1) * C + c] = b;
+  }
+}
+
+template <typename TX, typename TY>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_nchw_kernel(const TX* __restrict__ x, TY* __restrict__ y, int C,
+                                                                    int HW, const float* __restrict__ scale,
+                                                                    const float* __restrict__ shift, int relu,
+                                                                    const uint8_t* __restrict__ mask, float mask_scale) {
+  const int c = blockIdx.x % C;
+  const size_t base = (size_t)blockIdx.x * HW;
+  const int per = (HW + gridDim.y - 1) / gridDim.y;
+  const int p0 = blockIdx.y * per, p1 = min(HW, p0 + per);
+  const float sc = scale[c], sh = shift[c];
+  for (int p = p0 + threadIdx.x; p < p1; p += BN_THREADS) {
+    float t = fmaf(Elem<TX>::load(x + base + p), sc, sh);
+    if (relu) t = t > 0.f ? t : 0.f;
+    if (mask) t *= (float)mask[base + p] * mask_scale;
+    Elem<TY>::store(y + base + p, t);
+  }
+}
+
+template <typename TG, typename TX>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_nchw_kernel(
+    const TG* __restrict__ dz, const TX* __restrict__ x, TG* __restrict__ dx, int C, int HW,
+    const float* __restrict__ mean, const float* __restrict__ inv_std, const float* __restrict__ scale,
+    const float* __restrict__ shift, int relu, const uint8_t* __restrict__ mask, float mask_scale,
+    const float* __restrict__ gsums, int eval) {
+  const int c = blockIdx.x % C;
+  const size_t base = (size_t)blockIdx.x * HW;
+  const int per = (HW + gridDim.y - 1) / gridDim.y;
+  const int p0 = blockIdx.y * per, p1 = min(HW, p0 + per);
+  const float mu = mean[c], is = inv_std[c], sc = scale[c], sh = shift[c];
+  const float inv_count = eval ? 0.f : 1.f / gsums[2 * C];
+  const float k1 = eval ? 0.f : gsums[c] * inv_count, k2 = eval ? 0.f : gsums[C + c] * inv_count;
+  for (int p = p0 + threadIdx.x; p < p1; p += BN_THREADS) {
+    float g = Elem<TG>::load(dz + base + p);
+    const float v = Elem<TX>::load(x + base + p);
+    if (mask) g *= (float)mask[base + p] * mask_scale;
+    if (relu && !(fmaf(v, sc, sh) > 0.f)) g = 0.f;
+    const float o = eval ? sc * g : sc * (g - k1 - (v - mu) * is * k2);
+    Elem<TG>::store(dx + base + p, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void bn_reduce_kernel(const float* __restrict__ partials, int rows, int C, float count,
+                                 float* __restrict__ sums) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 2 * C) {
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += partials[(size_t)r * 2 * C + i];
+    sums[i] = s;
+  } else if (i == 2 * C) {
+    sums[i] = count;
+  }
+}
+
+__global__ void bn_coeffs_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float eps, float momentum, int legacy_clamp,
+                                 float* __restrict__ running_mean, float* __restrict__ running_var,
+                                 float* __restrict__ mean, float* __restrict__ inv_std, float* __restrict__ scale,
+                                 float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  // the final cancellation (sum of squares minus mean*sum) is done in double
+  const double cnt = (double)sums[2 * C];
+  const double s = (double)sums[c], q = (double)sums[C + c];
+  const double mu = s / cnt;
+  double sumvar = q - s * mu;
+  if (sumvar < 0.0) sumvar = 0.0;
+  const double var_b = sumvar / cnt;
+  const double var_u = sumvar / (cnt - 1.0);
+  const double is = legacy_clamp ? 1.0 / sqrt(var_b > (double)eps ? var_b : (double)eps) : 1.0 / sqrt(var_b + (double)eps);
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)var_u;
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float muf = (float)mu, isf = (float)is;
+  mean[c] = muf;
+  inv_std[c] = isf;
+  const float sc = g * isf;
+  scale[c] = sc;
+  shift[c] = b - muf * sc;
+}
+
+__global__ void bn_coeffs_eval_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                      float* __restrict__ mean, float* __restrict__ inv_std, float* __restrict__ scale,
+                                      float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mu = running_mean[c];
+  const float is = 1.f / sqrtf(running_var[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  mean[c] = mu;
+  inv_std[c] = is;
+  scale[c] = g * is;
+  shift[c] = b - mu * (g * is);
+}
+
+static bool aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
+
+static PmGeom pm_geom(int C, int vec) {
+  PmGeom g;
+  g.cg = C / vec;
+  g.rpb = BN_THREADS / g.cg;
+  return g;
+}
+
+static int pm_rows(long long M) {
+  long long r = (M + 255) / 256;
+  if (r < 1) r = 1;
+  if (r > BN_MAX_ROWS_PM) r = BN_MAX_ROWS_PM;
+  return (int)r;
+}
+
+static int nchw_rows(int N, int HW) {
+  long long r = ((long long)N * HW + 8191) / 8192;
+  if (r < 1) r = 1;
+  if (r > BN_MAX_ROWS_NCHW) r = BN_MAX_ROWS_NCHW;
+  if (r > HW) r = HW;
+  return (int)r;
+}
+
+static int apply_grid(long long work_items) {
+  long long b = (work_items + BN_THREADS - 1) / BN_THREADS;
+  if (b < 1) b = 1;
+  if (b > 8192) b = 8192;
+  return (int)b;
+}
+
+// slices of the pixel range per (n, c) plane for the NCHW apply kernels
+static int nchw_apply_slices(long long planes, int HW) {
+  if (planes >= 2048 || HW <= 4096) return 1;
+  long long s = (2048 + planes - 1) / planes;
+  long long cap = (HW + 4095) / 4096;
+  if (s > cap) s = cap;
+  if (s > 65535) s = 65535;
+  return (int)(s < 1 ? 1 : s);
+}
+
+}  // namespace segk
+
+using namespace segk;
+
+#define BN_COMMON_CHECK(name)                                                                                       \
+  SEGK_REQUIRE(N > 0 && C > 0 && HW > 0, name ": bad shape N=%d C=%d HW=%d", N, C, HW);                             \
+  SEGK_REQUIRE(layout == SEGK_PM || layout == SEGK_NCHW, name ": bad layout %d", layout);                           \
+  SEGK_REQUIRE(layout == SEGK_NCHW || C <= 1024, name ": pixel-major layout supports C <= 1024 (got %d)", C);        \
+  SEGK_REQUIRE(layout == SEGK_PM || (long long)N * C < 2147483647LL, name ": too many planes")
+
+extern "C" int segk_bn_stat_rows(int layout, int N, int C, int HW) {
+  (void)C;
+  if (N <= 0 || HW <= 0) return SEGK_INVALID_ARG;
+  return layout == SEGK_PM ? pm_rows((long long)N * HW) : nchw_rows(N, HW);
+}
+
+extern "C" int segk_bn_stats(const void* x, int dtype, int layout, int N, int C, int HW, int ld, float* partials,
+                             segk_stream_t stream) {
+  SEGK_REQUIRE(x && partials && valid_dtype(dtype), "bn_stats: null pointer or bad dtype");
+  BN_COMMON_CHECK("bn_stats");
+  hipStream_t st = (hipStream_t)stream;
+  if (layout == SEGK_PM) {
+    SEGK_REQUIRE(ld >= C, "bn_stats: ld %d < C %d", ld, C);
+    const long long M = (long long)N * HW;
+    const int rows = pm_rows(M);
+    const bool v4 = (C % 4 == 0) && (ld % 4 == 0) && aligned(x, dtype == SEGK_BF16 ? 8 : 16) && C / 4 <= BN_THREADS;
+    SEGK_REQUIRE(v4 || C <= BN_THREADS, "bn_stats: C=%d needs 4-element alignment in pixel-major layout", C);
+    SEGK_DISPATCH_DTYPE(dtype, T, {
+      if (v4)
+        bn_stats_pm_kernel<T, 4><<<rows, BN_THREADS, 0, st>>>((const T*)x, ld, M, C, pm_geom(C, 4), partials);
+      else
+        bn_stats_pm_kernel<T, 1><<<rows, BN_THREADS, 0, st>>>((const T*)x, ld, M, C, pm_geom(C, 1), partials);
+    });
+  } else {
+    SEGK_REQUIRE(C <= 2147483647, "bn_stats: C too large");
+    dim3 grid(C, nchw_rows(N, HW));
+    SEGK_DISPATCH_DTYPE(dtype, T, (bn_stats_nchw_kernel<T><<<grid, BN_THREADS, 0, st>>>((const T*)x, N, C, HW, partials)));
+  }
+  SEGK_CHECK_LAUNCH("bn_stats");
+  return SEGK_OK;
+}
+
+extern "C" int segk_bn_reduce(const float* partials, int rows, int C, float count, float* sums, segk_stream_t stream) {
+  SEGK_REQUIRE(partials && sums && rows > 0 && C > 0, "bn_reduce: bad arguments rows=%d C=%d", rows, C);
+  bn_reduce_kernel<<<ceil_div(2 * C + 1, 256), 256, 0, (hipStream_t)stream>>>(partials, rows, C, count, sums);
+  SEGK_CHECK_LAUNCH("bn_reduce");
+  return SEGK_OK;
+}
+
+extern "C" int segk_bn_coeffs(const float* sums, const float* gamma, const float* beta, float eps, float momentum,
+                              int legacy_clamp, float* running_mean, float* running_var, float* mean, float* inv_std,
+                              float* scale, float* shift, int C, segk_stream_t stream) {
+  SEGK_REQUIRE(sums && mean && inv_std && scale && shift && C > 0, "bn_coeffs: null pointer or C=%d", C);
+  bn_coeffs_kernel<<<ceil_div(C, 256), 256, 0, (hipStream_t)stream>>>(sums, gamma, beta, eps, momentum, legacy_clamp,
+                                                                      running_mean, running_var, mean, inv_std, scale,
+                                                                      shift, C);
+  SEGK_CHECK_LAUNCH("bn_coeffs");
+  return SEGK_OK;
+}
+
+extern "C" int segk_bn_coeffs_eval(const float* running_mean, const float* running_var, const float* gamma,
+                                   const float* beta, float eps, float* mean, float* inv_std, float* scale,
+                                   float* shift, int C, segk_stream_t stream) {
+  SEGK_REQUIRE(running_mean && running_var && mean && inv_std && scale && shift && C > 0,
+               "bn_coeffs_eval: null pointer or C=%d", C);
+  bn_coeffs_eval_kernel<<<ceil_div(C, 256), 256, 0, (hipStream_t)stream>>>(running_mean, running_var, gamma, beta, eps,
+                                                                           mean, inv_std, scale, shift, C);
+  SEGK_CHECK_LAUNCH("bn_coeffs_eval");
+  return SEGK_OK;
+}
+
+extern "C" int segk_bn_apply(const void* x, int x_dtype, int x_ld, void* y, int y_dtype, int y_ld, int layout, int N,
+                             int C, int HW, const float* scale, const float* shift, int relu, const uint8_t* mask,
+                             float mask_scale, segk_stream_t stream) {
+  SEGK_REQUIRE(x && y && scale && shift && valid_dtype(x_dtype) && valid_dtype(y_dtype),
+               "bn_apply: null pointer or bad dtype");
+  BN_COMMON_CHECK("bn_apply");
+  hipStream_t st = (hipStream_t)stream;
+  if (layout == SEGK_PM) {
+    SEGK_REQUIRE(x_ld >= C && y_ld >= C, "bn_apply: ld (%d,%d) < C %d", x_ld, y_ld, C);
+    const long long M = (long long)N * HW;
+    const bool v4 = (C % 4 == 0) && (x_ld % 4 == 0) && (y_ld % 4 == 0) && aligned(x, x_dtype == SEGK_BF16 ? 8 : 16) &&
+                    aligned(y, y_dtype == SEGK_BF16 ? 8 : 16) && (!mask || aligned(mask, 4));
+    const int vec = v4 ? 4 : 1;
+    const int cg = C / vec;
+    const int grid = apply_grid(M * cg);
+#define LAUNCH_APPLY(TX, TY)                                                                                     \
+  if (v4)                                                                                                        \
+    bn_apply_pm_kernel<TX, TY, 4><<<grid, BN_THREADS, 0, st>>>((const TX*)x, x_ld, (TY*)y, y_ld, M, C, cg, scale, \
+                                                               shift, relu, mask, mask_scale);                   \
+  else                                                                                                           \
+    bn_apply_pm_kernel<TX, TY, 1><<<grid, BN_THREADS, 0, st>>>((const TX*)x, x_ld, (TY*)y, y_ld, M, C, cg, scale, \
+                                                               shift, relu, mask, mask_scale)
+    if (x_dtype == SEGK_BF16 && y_dtype == SEGK_BF16) { LAUNCH_APPLY(bf16_t, bf16_t); }
+    else if (x_dtype == SEGK_BF16) { LAUNCH_APPLY(bf16_t, float); }
+    else if (y_dtype == SEGK_BF16) { LAUNCH_APPLY(float, bf16_t); }
+    else { LAUNCH_APPLY(float, float); }
+#undef LAUNCH_APPLY
+  } else {
+    const long long planes = (long long)N * C;
+    dim3 grid((unsigned)planes, nchw_apply_slices(planes, HW));
+#define LAUNCH_APPLY(TX, TY) \
+  bn_apply_nchw_kernel<TX, TY><<<grid, BN_THREADS, 0, st>>>((const TX*)x, (TY*)y, C, HW, scale, shift, relu, mask, mask_scale)
+    if (x_dtype == SEGK_BF16 && y_dtype == SEGK_BF16) { LAUNCH_APPLY(bf16_t, bf16_t); }
+    else if (x_dtype == SEGK_BF16) { LAUNCH_APPLY(bf16_t, float); }
+    else if (y_dtype == SEGK_BF16) { LAUNCH_APPLY(float, bf16_t); }
+    else { LAUNCH_APPLY(float, float); }
+#undef LAUNCH_APPLY
+  }
+  SEGK_CHECK_LAUNCH("bn_apply");
+  return SEGK_OK;
+}
+
+extern "C" int segk_bn_bwd_stats(const void* dz, int dz_dtype, int dz_ld, const void* x, int x_dtype, int x_ld,
+                                 int layout, int N, int C, int HW, const float* mean, const float* inv_std,
+                                 const float* scale, const float* shift, int relu, const uint8_t* mask,
+                                 float mask_scale, float* partials, segk_stream_t stream) {
+  SEGK_REQUIRE(dz && x && mean && inv_std && scale && shift && partials && valid_dtype(dz_dtype) && valid_dtype(x_dtype),
+               "bn_bwd_stats: null pointer or bad dtype");
+  BN_COMMON_CHECK("bn_bwd_stats");
+  hipStream_t st = (hipStream_t)stream;
+  if (layout == SEGK_PM) {
+    SEGK_REQUIRE(x_ld >= C && dz_ld >= C, "bn_bwd_stats: ld (%d,%d) < C %d", dz_ld, x_ld, C);
+    const long long M = (long long)N * HW;
+    const int rows = pm_rows(M);
+    const bool v4 = (C % 4 == 0) && (x_ld % 4 == 0) && (dz_ld % 4 == 0) && aligned(x, x_dtype == SEGK_BF16 ? 8 : 16) &&
+                    aligned(dz, dz_dtype == SEGK_BF16 ? 8 : 16) && (!mask || aligned(mask, 4)) && C / 4 <= BN_THREADS;
+    SEGK_REQUIRE(v4 || C <= BN_THREADS, "bn_bwd_stats: C=%d needs 4-element alignment in pixel-major layout", C);
+#define LAUNCH_BS(TG, TX)                                                                                           \
+  if (v4)                                                                                                           \
+    bn_bwd_stats_pm_kernel<TG, TX, 4><<<rows, BN_THREADS, 0, st>>>((const TG*)dz, dz_ld, (const TX*)x, x_ld, M, C,   \
+                                                                   pm_geom(C, 4), mean, inv_std, scale, shift, relu, \
+                                                                   mask, mask_scale, partials);                     \
+  else                                                                                                              \
+    bn_bwd_stats_pm_kernel<TG, TX, 1><<<rows, BN_THREADS, 0, st>>>((const TG*)dz, dz_ld, (const TX*)x, x_ld, M, C,   \
+                                                                   pm_geom(C, 1), mean, inv_std, scale, shift, relu, \
+                                                                   mask, mask_scale, partials)
+    if (dz_dtype == SEGK_BF16 && x_dtype == SEGK_BF16) { LAUNCH_BS(bf16_t, bf16_t); }
+    else if (dz_dtype == SEGK_BF16) { LAUNCH_BS(bf16_t, float); }
+    else if (x_dtype == SEGK_BF16) { LAUNCH_BS(float, bf16_t); }
+    else { LAUNCH_BS(float, float); }
+#undef LAUNCH_BS
+  } else {
+    dim3 grid(C, nchw_rows(N, HW));
+#define LAUNCH_BS(TG, TX)                                                                                        \
+  bn_bwd_stats_nchw_kernel<TG, TX><<<grid, BN_THREADS, 0, st>>>((const TG*)dz, (const TX*)x, N, C, HW, mean, inv_std, \
+                                                                scale, shift, relu, mask, mask_scale, partials)
+    if (dz_dtype == SEGK_BF16 && x_dtype == SEGK_BF16) { LAUNCH_BS(bf16_t, bf16_t); }
+    else if (dz_dtype == SEGK_BF16) { LAUNCH_BS(bf16_t, float); }
+    else if (x_dtype == SEGK_BF16) { LAUNCH_BS(float, bf16_t); }
+    else { LAUNCH_BS(float, float); }
+#undef LAUNCH_BS
+  }
+  SEGK_CHECK_LAUNCH("bn_bwd_stats");
+  return SEGK_OK;
+}
+
+extern "C" int segk_bn_bwd_apply(const void* dz, int dz_dtype, int dz_ld, const void* x, int x_dtype, int x_ld, void* dx,
+                                 int dx_dtype, int dx_ld, int layout, int N, int C, int HW, const float* mean,
+                                 const float* inv_std, const float* scale, const float* shift, int relu,
+                                 const uint8_t* mask, float mask_scale, const float* gsums, int eval,
+                                 segk_stream_t stream) {
+  SEGK_REQUIRE(dz && x && dx && mean && inv_std && scale && shift && valid_dtype(dz_dtype) && valid_dtype(x_dtype),
+               "bn_bwd_apply: null pointer or bad dtype");
+  SEGK_REQUIRE(dx_dtype == dz_dtype, "bn_bwd_apply: dx dtype must equal dz dtype");
+  SEGK_REQUIRE(eval || gsums, "bn_bwd_apply: training mode needs the global sums");
+  BN_COMMON_CHECK("bn_bwd_apply");
+  hipStream_t st = (hipStream_t)stream;
+  if (layout == SEGK_PM) {
+    SEGK_REQUIRE(x_ld >= C && dz_ld >= C && dx_ld >= C, "bn_bwd_apply: ld (%d,%d,%d) < C %d", dz_ld, x_ld, dx_ld, C);
+    const long long M = (long long)N * HW;
+    const size_t ga = dz_dtype == SEGK_BF16 ? 8 : 16;
+    const bool v4 = (C % 4 == 0) && (x_ld % 4 == 0) && (dz_ld % 4 == 0) && (dx_ld % 4 == 0) &&
+                    aligned(x, x_dtype == SEGK_BF16 ? 8 : 16) && aligned(dz, ga) && aligned(dx, ga) &&
+                    (!mask || aligned(mask, 4));
+    const int vec = v4 ? 4 : 1;
+    const int cg = C / vec;
+    const int grid = apply_grid(M * cg);
+#define LAUNCH_BA(TG, TX)                                                                                            \
+  if (v4)                                                                                                            \
+    bn_bwd_apply_pm_kernel<TG, TX, 4><<<grid, BN_THREADS, 0, st>>>((const TG*)dz, dz_ld, (const TX*)x, x_ld, (TG*)dx, \
+                                                                   dx_ld, M, C, cg, mean, inv_std, scale, shift, relu, \
+                                                                   mask, mask_scale, gsums, eval);                   \
+  else                                                                                                               \
+    bn_bwd_apply_pm_kernel<TG, TX, 1><<<grid, BN_THREADS, 0, st>>>((const TG*)dz, dz_ld, (const TX*)x, x_ld, (TG*)dx, \
+                                                                   dx_ld, M, C, cg, mean, inv_std, scale, shift, relu, \
+                                                                   mask, mask_scale, gsums, eval)
+    if (dz_dtype == SEGK_BF16 && x_dtype == SEGK_BF16) { LAUNCH_BA(bf16_t, bf16_t); }
+    else if (dz_dtype == SEGK_BF16) { LAUNCH_BA(bf16_t, float); }
+    else if (x_dtype == SEGK_BF16) { LAUNCH_BA(float, bf16_t); }
+    else { LAUNCH_BA(float, float); }
+#undef LAUNCH_BA
+  } else {
+    const long long planes = (long long)N * C;
+    dim3 grid((unsigned)planes, nchw_apply_slices(planes, HW));
+#define LAUNCH_BA(TG, TX)                                                                                          \
+  bn_bwd_apply_nchw_kernel<TG, TX><<<grid, BN_THREADS, 0, st>>>((const TG*)dz, (const TX*)x, (TG*)dx, C, HW, mean,  \
+                                                                inv_std, scale, shift, relu, mask, mask_scale, gsums, \
+                                                                eval)
+    if (dz_dtype == SEGK_BF16 && x_dtype == SEGK_BF16) { LAUNCH_BA(bf16_t, bf16_t); }
+    else if (dz_dtype == SEGK_BF16) { LAUNCH_BA(bf16_t, float); }
+    else if (x_dtype == SEGK_BF16) { LAUNCH_BA(float, bf16_t); }
+    else { LAUNCH_BA(float, float); }
+#undef LAUNCH_BA
+  }
+  SEGK_CHECK_LAUNCH("bn_bwd_apply");
+  return SEGK_OK;
+}

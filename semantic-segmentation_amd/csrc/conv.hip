@@ -1,0 +1,666 @@
+// Convolution as implicit GEMM on the CDNA4 matrix cores.
+//
+// Forward / data gradient (conv_fwd_kernel):  out[m][co] = sum_seg sum_tap sum_c in[m + tap][c] * w[tap][co][c]
+//   GEMM view: rows = output channels (MFMA A operand = packed weights, K-contiguous),
+//              cols = pixels         (MFMA B operand = pixel-major activations, K-contiguous),
+//              K    = (segment, tap, channel).  A 128(co) x 128(pixel) tile per workgroup, 4 wavefronts in a
+//   2x2 grid, each owning 64x64 = 4x4 MFMA 16x16 tiles.  Both operand tiles are staged through LDS as
+//   [128 rows][BKB bytes] with a 16-byte-chunk XOR swizzle so the ds_read_b128 fragment reads are
+//   conflict-free.  Taps whose shifted window lies outside the image for every pixel of the tile are skipped
+//   (atrous rates comparable to the map size make most off-centre taps empty).
+//   bf16: v_mfma_f32_16x16x32_bf16; fp32: v_mfma_f32_16x16x4_f32 (exact fp32 fma chain).
+//
+// Weight gradient (conv_wgrad_kernel): dw[tap][ci][co] = sum_m dout[m][co] * in[m + tap][ci]
+//   GEMM view: rows = co, cols = ci, K = pixels.  Operands are pixel-major, i.e. K is the slow index, so
+//   bf16 fragments are read with the transposing ds_read_b64_tr_b16 and fp32 fragments with ds_read_b32.
+//   The pixel range is split over workgroups; each split writes its own fp32 slab (summed later in fixed
+//   order, so results are reproducible: no float atomics).
+#include "common.h"
+
+namespace segk {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+constexpr int CONV_THREADS = 256;
+constexpr int TILE = 128;  // both GEMM tile edges
+
+struct SegDev {
+  const char* in;
+  const char* w;
+  long long in_ld_b;  // bytes between pixels
+  long long w_tap_b;  // bytes between taps of the packed weight
+  int ck_b;           // contracted bytes per (pixel, tap)
+  int R, dil;
+};
+
+struct ConvDev {
+  int H, W, HW;
+  long long M;
+  int Cout, nseg, n_tiles;
+  SegDev seg[SEGK_MAX_SEG];
+  char* out;
+  int out_ld;
+  const float* bias;
+  const float* img_bias;
+  float* stat;
+};
+
+template <typename T>
+struct Mma;
+template <>
+struct Mma<bf16_t> {
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <>
+struct Mma<float> {
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(b[e]), c, 0, 0, 0);
+  }
+};
+
+// byte offset of 16-byte chunk c of row r in a [128][BKB] tile
+template <int BKB>
+__device__ __forceinline__ int tile_off(int r, int c) {
+  if (BKB == 128) return r * 128 + ((c ^ (r & 7)) << 4);
+  return r * 64 + ((c ^ ((-(r >> 2)) & 3)) << 4);
+}
+
+template <typename TO>
+__device__ __forceinline__ void store_out4(char* p, const float (&v)[4]);
+template <>
+__device__ __forceinline__ void store_out4<float>(char* p, const float (&v)[4]) {
+  f32x4 t = {v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(p) = t;
+}
+template <>
+__device__ __forceinline__ void store_out4<bf16_t>(char* p, const float (&v)[4]) {
+  u32x2 t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+  *reinterpret_cast<u32x2*>(p) = t;
+}
+
+template <typename T, int BKB, typename TO>
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv_fwd_kernel(const ConvDev p) {
+  constexpr int CH = BKB / 16;               // 16-byte chunks per tile row
+  constexpr int RPP = CONV_THREADS / CH;     // rows loaded per pass
+  constexpr int NP = TILE / RPP;             // passes per operand tile
+  constexpr int TILE_B = TILE * BKB;
+  constexpr int KS = BKB / 64;               // MFMA k-steps per tile (one 16-byte chunk per lane per step)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int taps_l[SEGK_MAX_SEG * 9];
+  __shared__ int ntaps_l[SEGK_MAX_SEG];
+  __shared__ unsigned int mask_l[2];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;   // wave row (channels) / column (pixels) in the 2x2 grid
+  const int nt = blockIdx.x % p.n_tiles;
+  const long long mt = blockIdx.x / p.n_tiles;
+  const int co0 = nt * TILE;
+  const long long m0 = mt * TILE;
+
+  const int lc = tid % CH, lr = tid / CH;
+  int wrow[NP], ry[NP], rx[NP];
+  long long rm[NP];
+  bool rvalid[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int row = lr + i * RPP;
+    int co = co0 + row;
+    wrow[i] = co < p.Cout ? co : p.Cout - 1;
+    const long long m = m0 + row;
+    rvalid[i] = m < p.M;
+    const long long mm = rvalid[i] ? m : 0;
+    rm[i] = mm;
+    const int rem = (int)(mm % p.HW);
+    ry[i] = rem / p.W;
+    rx[i] = rem - ry[i] * p.W;
+  }
+
+  // ---- which taps touch this tile at all -------------------------------------------------
+  if (tid < 2) mask_l[tid] = 0u;
+  __syncthreads();
+  {
+    unsigned long long mine = 0ull;
+    for (int sg = 0; sg < p.nseg; ++sg) {
+      const int R = p.seg[sg].R, dil = p.seg[sg].dil;
+      for (int tap = 0; tap < R * R; ++tap) {
+        const int dy = (tap / R - (R >> 1)) * dil, dx = (tap % R - (R >> 1)) * dil;
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+          any |= rvalid[i] && (unsigned)(ry[i] + dy) < (unsigned)p.H && (unsigned)(rx[i] + dx) < (unsigned)p.W;
+        if (any) mine |= 1ull << (sg * 9 + tap);
+      }
+    }
+    const unsigned int lo = (unsigned int)mine, hi = (unsigned int)(mine >> 32);
+    if (lo) atomicOr(&mask_l[0], lo);
+    if (hi) atomicOr(&mask_l[1], hi);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned long long all = ((unsigned long long)mask_l[1] << 32) | mask_l[0];
+    for (int sg = 0; sg < p.nseg; ++sg) {
+      int cnt = 0;
+      const int R = p.seg[sg].R;
+      for (int tap = 0; tap < R * R; ++tap)
+        if ((all >> (sg * 9 + tap)) & 1ull) taps_l[sg * 9 + cnt++] = tap;
+      ntaps_l[sg] = cnt;
+    }
+  }
+  __syncthreads();
+  int total = 0;
+  for (int sg = 0; sg < p.nseg; ++sg) total += ntaps_l[sg] * (p.seg[sg].ck_b / BKB);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (total > 0) {
+    // ---- K-loop state ---------------------------------------------------------------------
+    int sg = 0;
+    while (ntaps_l[sg] == 0) ++sg;
+    int ti = 0, kc = 0, nkc = p.seg[sg].ck_b / BKB;
+    const char* aptr[NP];
+    const char* bptr[NP];
+    bool bok[NP];
+    auto setup_tap = [&]() {
+      const SegDev& s = p.seg[sg];
+      const int tap = taps_l[sg * 9 + ti];
+      const int R = s.R;
+      const int dy = (tap / R - (R >> 1)) * s.dil, dx = (tap % R - (R >> 1)) * s.dil;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        aptr[i] = s.w + (long long)tap * s.w_tap_b + (long long)wrow[i] * s.ck_b + lc * 16;
+        bok[i] = rvalid[i] && (unsigned)(ry[i] + dy) < (unsigned)p.H && (unsigned)(rx[i] + dx) < (unsigned)p.W;
+        bptr[i] = s.in + (rm[i] + (long long)dy * p.W + dx) * s.in_ld_b + lc * 16;
+      }
+    };
+    auto advance = [&]() {
+      if (++kc < nkc) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          aptr[i] += BKB;
+          bptr[i] += BKB;
+        }
+        return;
+      }
+      kc = 0;
+      if (++ti >= ntaps_l[sg]) {
+        ti = 0;
+        ++sg;
+        while (ntaps_l[sg] == 0) ++sg;
+        nkc = p.seg[sg].ck_b / BKB;
+      }
+      setup_tap();
+    };
+    u32x4 ra[NP], rb[NP];
+    auto load_tile = [&]() {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) ra[i] = *reinterpret_cast<const u32x4*>(aptr[i]);
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        u32x4 z = {0u, 0u, 0u, 0u};
+        rb[i] = bok[i] ? *reinterpret_cast<const u32x4*>(bptr[i]) : z;
+      }
+    };
+    auto store_tile = [&](int stage) {
+      char* sa = smem + stage * 2 * TILE_B;
+      char* sb = sa + TILE_B;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int off = tile_off<BKB>(lr + i * RPP, lc);
+        *reinterpret_cast<u32x4*>(sa + off) = ra[i];
+        *reinterpret_cast<u32x4*>(sb + off) = rb[i];
+      }
+    };
+
+    setup_tap();
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+    const int frow = lane & 15, fg = lane >> 4;
+    for (int st = 0; st < total; ++st) {
+      const int cur = st & 1;
+      const bool more = st + 1 < total;
+      if (more) {
+        advance();
+        load_tile();
+      }
+      const char* sa = smem + cur * 2 * TILE_B;
+      const char* sb = sa + TILE_B;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        u32x4 fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          fa[i] = *reinterpret_cast<const u32x4*>(sa + tile_off<BKB>(wr * 64 + i * 16 + frow, ks * 4 + fg));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          fb[j] = *reinterpret_cast<const u32x4*>(sb + tile_off<BKB>(wc * 64 + j * 16 + frow, ks * 4 + fg));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+      }
+      if (more) store_tile(cur ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: acc[i][j][r] = out[pixel = wc*64 + j*16 + (lane&15)][co = wr*64 + i*16 + (lane>>4)*4 + r]
+  const int fq = lane >> 4, fr = lane & 15;
+  if (p.stat) {
+    float* red = reinterpret_cast<float*>(smem);  // [2 pixel halves][2][128]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s[4], q[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[r] = 0.f;
+        q[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = acc[i][j][r];
+          s[r] += v;
+          q[r] = fmaf(v, v, q[r]);
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          s[r] += __shfl_xor(s[r], o, 64);
+          q[r] += __shfl_xor(q[r], o, 64);
+        }
+      }
+      if (fr == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cl = wr * 64 + i * 16 + fq * 4 + r;
+          red[(wc * 2 + 0) * TILE + cl] = s[r];
+          red[(wc * 2 + 1) * TILE + cl] = q[r];
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * TILE) {
+      const int which = tid / TILE, cl = tid % TILE;
+      const int co = co0 + cl;
+      if (co < p.Cout) p.stat[((size_t)mt * 2 + which) * p.Cout + co] = red[which * TILE + cl] + red[(2 + which) * TILE + cl];
+    }
+  }
+
+  const int cpad = (p.Cout + 3) & ~3;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long long m = m0 + wc * 64 + j * 16 + fr;
+    if (m >= p.M) continue;
+    const long long n = m / p.HW;
+    char* orow = p.out + (size_t)m * p.out_ld * sizeof(TO);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = co0 + wr * 64 + i * 16 + fq * 4;
+      if (c >= cpad) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = acc[i][j][r];
+        if (c + r < p.Cout) {
+          if (p.bias) t += p.bias[c + r];
+          if (p.img_bias) t += p.img_bias[n * p.Cout + c + r];
+        } else {
+          t = 0.f;
+        }
+        v[r] = t;
+      }
+      store_out4<TO>(orow + (size_t)c * sizeof(TO), v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient
+// ------------------------------------------------------------------------------------------------
+struct WgradDev {
+  int H, W, HW;
+  long long M;
+  const char* in;
+  const char* dout;
+  long long in_ld_b, dout_ld_b;
+  int Cin, Cout, R, dil, splits;
+  int co_tiles, ci_tiles;
+  long long per_split;  // pixels per split (multiple of the pixel chunk)
+  float* slabs;
+};
+
+// Tile = [BP pixels][128 channels]; row bytes RB = 128*sizeof(T).
+// bf16: 32-byte granules XOR-swizzled by f(row) so that the transposing reads of 8 pixel rows x 32 bytes
+//       cover one 256-byte bank window exactly; fp32: 16-float halves swapped on odd rows for ds_read_b32.
+template <typename T>
+__device__ __forceinline__ int wg_chunk_off(int row, int c16);  // byte offset of 16-byte chunk c16 of row
+template <>
+__device__ __forceinline__ int wg_chunk_off<bf16_t>(int row, int c16) {
+  const int f = (row & 3) | ((row >> 1) & 4);
+  return row * 256 + ((((c16 >> 1) ^ f) & 7) << 5) + ((c16 & 1) << 4);
+}
+template <>
+__device__ __forceinline__ int wg_chunk_off<float>(int row, int c16) {
+  return row * 512 + ((c16 ^ ((row & 1) << 2)) << 4);
+}
+
+template <typename T>
+struct WgFrag;
+// bf16: one MFMA k-step = 32 pixels.  Fragment for 16 channels starting at ch0 (multiple of 16).
+template <>
+struct WgFrag<bf16_t> {
+  static constexpr int BP = 64;       // pixels per tile
+  static constexpr int KSTEPS = 2;    // 32 pixels each
+  static __device__ __forceinline__ u32x4 read(const char* tile, int ks, int ch0, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int c32 = ch0 >> 4;
+    u32x4 out;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = ks * 32 + g * 8 + h * 4 + q;
+      const int f = (row & 3) | ((row >> 1) & 4);
+      const int off = row * 256 + (((c32 ^ f) & 7) << 5) + pp * 8;
+      s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(__attribute__((address_space(3))) char*)(tile + off));
+      u32x2 u = __builtin_bit_cast(u32x2, v);
+      out[2 * h] = u[0];
+      out[2 * h + 1] = u[1];
+    }
+    return out;
+  }
+  static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+// fp32: one MFMA k-step = 4 pixels; the "fragment" packs 4 consecutive k-steps (16 pixels) in a u32x4.
+template <>
+struct WgFrag<float> {
+  static constexpr int BP = 32;
+  static constexpr int KSTEPS = 2;    // 16 pixels each (4 MFMAs)
+  static __device__ __forceinline__ u32x4 read(const char* tile, int ks, int ch0, int lane) {
+    const int g = lane >> 4, col = ch0 + (lane & 15);
+    u32x4 out;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = ks * 16 + e * 4 + g;
+      const int off = row * 512 + ((col ^ ((row & 1) << 4)) << 2);
+      out[e] = *reinterpret_cast<const unsigned int*>(tile + off);
+    }
+    return out;
+  }
+  static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(b[e]), c, 0, 0, 0);
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv_wgrad_kernel(const WgradDev p) {
+  constexpr int BP = WgFrag<T>::BP;
+  constexpr int RB = TILE * (int)sizeof(T);      // tile row bytes
+  constexpr int CH = RB / 16;                    // 16-byte chunks per row (16 bf16 / 32 fp32)
+  constexpr int RPP = CONV_THREADS / CH;         // rows per pass
+  constexpr int NP = BP / RPP;                   // passes (4 for both dtypes)
+  constexpr int TILE_B = BP * RB;                // 16 KB
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][dout tile | in tile]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  int b = blockIdx.x;
+  const int cot = b % p.co_tiles; b /= p.co_tiles;
+  const int cit = b % p.ci_tiles; b /= p.ci_tiles;
+  const int taps = p.R * p.R;
+  const int tap = b % taps;
+  const int sp = b / taps;
+  const int co0 = cot * TILE, ci0 = cit * TILE;
+  const int dy = (tap / p.R - (p.R >> 1)) * p.dil, dx = (tap % p.R - (p.R >> 1)) * p.dil;
+  const long long pbeg = (long long)sp * p.per_split;
+  long long pend = pbeg + p.per_split;
+  if (pend > p.M) pend = p.M;
+  const int nchunks = pbeg < pend ? (int)((pend - pbeg + BP - 1) / BP) : 0;
+
+  const int lc = tid % CH, lr = tid / CH;
+  const int esz = (int)sizeof(T);
+  const int ch_per_chunk = 16 / esz;
+  const bool d_ok = co0 + lc * ch_per_chunk < p.Cout;  // Cout, Cin are multiples of 16 / 32 elements
+  const bool x_ok = ci0 + lc * ch_per_chunk < p.Cin;
+  const char* dbase = p.dout + (size_t)(co0 + lc * ch_per_chunk) * esz;
+  const char* xbase = p.in + (size_t)(ci0 + lc * ch_per_chunk) * esz;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 rd[NP], rx[NP];
+  // load chunk `ck`; returns whether any of this thread's shifted rows is inside the image
+  auto load_chunk = [&](int ck) -> int {
+    int any = 0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const long long m = pbeg + (long long)ck * BP + lr + i * RPP;
+      u32x4 z = {0u, 0u, 0u, 0u};
+      rd[i] = z;
+      rx[i] = z;
+      if (m < pend) {
+        const int rem = (int)(m % p.HW);
+        const int y = rem / p.W, x = rem - y * p.W;
+        const bool in_img = (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W;
+        if (in_img) {
+          any = 1;
+          if (d_ok) rd[i] = *reinterpret_cast<const u32x4*>(dbase + m * p.dout_ld_b);
+          if (x_ok) rx[i] = *reinterpret_cast<const u32x4*>(xbase + (m + (long long)dy * p.W + dx) * p.in_ld_b);
+        }
+      }
+    }
+    return any;
+  };
+  auto store_chunk = [&](int stage) {
+    char* sd = smem + stage * 2 * TILE_B;
+    char* sx = sd + TILE_B;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int off = wg_chunk_off<T>(lr + i * RPP, lc);
+      *reinterpret_cast<u32x4*>(sd + off) = rd[i];
+      *reinterpret_cast<u32x4*>(sx + off) = rx[i];
+    }
+  };
+
+  if (nchunks > 0) {
+    int any = load_chunk(0);
+    store_chunk(0);
+    int cur_any = __syncthreads_or(any);
+    for (int ck = 0; ck < nchunks; ++ck) {
+      const int cur = ck & 1;
+      const bool more = ck + 1 < nchunks;
+      any = 0;
+      if (more) any = load_chunk(ck + 1);
+      if (cur_any) {
+        const char* sd = smem + cur * 2 * TILE_B;
+        const char* sx = sd + TILE_B;
+#pragma unroll
+        for (int ks = 0; ks < WgFrag<T>::KSTEPS; ++ks) {
+          u32x4 fa[4], fb[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) fa[i] = WgFrag<T>::read(sd, ks, wr * 64 + i * 16, lane);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fb[j] = WgFrag<T>::read(sx, ks, wc * 64 + j * 16, lane);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) WgFrag<T>::mma(fa[i], fb[j], acc[i][j]);
+        }
+      }
+      if (more) store_chunk(cur ^ 1);
+      cur_any = __syncthreads_or(any);
+    }
+  }
+
+  // acc[i][j][r] = dw[co = co0 + wr*64 + i*16 + (lane>>4)*4 + r][ci = ci0 + wc*64 + j*16 + (lane&15)]
+  const int fq = lane >> 4, fr = lane & 15;
+  float* slab = p.slabs + ((size_t)sp * taps + tap) * p.Cin * p.Cout;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ci = ci0 + wc * 64 + j * 16 + fr;
+    if (ci >= p.Cin) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = co0 + wr * 64 + i * 16 + fq * 4;
+      if (co >= p.Cout) continue;
+      *reinterpret_cast<f32x4*>(slab + (size_t)ci * p.Cout + co) = acc[i][j];
+    }
+  }
+}
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+template <typename K>
+static int set_lds(K kernel, int bytes, const char* name) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    set_error("%s: hipFuncSetAttribute(%d bytes LDS): %s", name, bytes, hipGetErrorString(e));
+    return SEGK_HIP_ERROR;
+  }
+  return SEGK_OK;
+}
+
+template <typename T, int BKB, typename TO>
+static int launch_fwd(const ConvDev& d, int blocks, hipStream_t st) {
+  const int lds = 4 * TILE * BKB;
+  static bool configured = false;  // per instantiation
+  if (!configured) {
+    int rc = set_lds(conv_fwd_kernel<T, BKB, TO>, lds, "conv_fwd");
+    if (rc != SEGK_OK) return rc;
+    configured = true;
+  }
+  conv_fwd_kernel<T, BKB, TO><<<blocks, CONV_THREADS, lds, st>>>(d);
+  return SEGK_OK;
+}
+
+}  // namespace segk
+
+using namespace segk;
+
+static int conv_check(const segk_conv_args* a) {
+  SEGK_REQUIRE(a, "conv: null args");
+  SEGK_REQUIRE(valid_dtype(a->dtype) && valid_dtype(a->out_dtype), "conv: bad dtype");
+  SEGK_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->Cout > 0, "conv: bad shape N=%d H=%d W=%d Cout=%d", a->N, a->H,
+               a->W, a->Cout);
+  SEGK_REQUIRE(a->nseg >= 1 && a->nseg <= SEGK_MAX_SEG, "conv: nseg=%d", a->nseg);
+  SEGK_REQUIRE(a->out && a->out_ld >= ((a->Cout + 3) & ~3) && a->out_ld % 4 == 0,
+               "conv: out_ld=%d must be a multiple of 4 and >= Cout rounded up to 4 (Cout=%d)", a->out_ld, a->Cout);
+  SEGK_REQUIRE(((uintptr_t)a->out % (a->out_dtype == SEGK_BF16 ? 8 : 16)) == 0, "conv: output base misaligned");
+  const int es = dtype_size(a->dtype);
+  for (int s = 0; s < a->nseg; ++s) {
+    const segk_conv_seg& g = a->seg[s];
+    SEGK_REQUIRE(g.in && g.w && aligned16(g.in) && aligned16(g.w), "conv: segment %d pointers null or not 16-byte aligned", s);
+    SEGK_REQUIRE(g.R == 1 || g.R == 3, "conv: segment %d kernel size %d (1 or 3)", s, g.R);
+    SEGK_REQUIRE(g.dil >= 1, "conv: segment %d dilation %d", s, g.dil);
+    SEGK_REQUIRE(g.Ck > 0 && g.Ck % 32 == 0 && g.Ck <= g.in_ld, "conv: segment %d Ck=%d must be a multiple of 32 and <= ld=%d",
+                 s, g.Ck, g.in_ld);
+    SEGK_REQUIRE(((long long)g.in_ld * es) % 16 == 0, "conv: segment %d row stride not a multiple of 16 bytes", s);
+  }
+  return SEGK_OK;
+}
+
+extern "C" int segk_conv_stat_rows(const segk_conv_args* a) {
+  if (!a || a->N <= 0 || a->H <= 0 || a->W <= 0) return SEGK_INVALID_ARG;
+  return ceil_div((long long)a->N * a->H * a->W, TILE);
+}
+
+extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
+  int rc = conv_check(a);
+  if (rc != SEGK_OK) return rc;
+  ConvDev d;
+  d.H = a->H; d.W = a->W; d.HW = a->H * a->W;
+  d.M = (long long)a->N * d.HW;
+  d.Cout = a->Cout; d.nseg = a->nseg;
+  d.n_tiles = ceil_div(a->Cout, TILE);
+  const int es = dtype_size(a->dtype);
+  bool wide = true;
+  for (int s = 0; s < SEGK_MAX_SEG; ++s) {
+    const segk_conv_seg& g = a->seg[s < a->nseg ? s : 0];
+    d.seg[s].in = (const char*)g.in;
+    d.seg[s].w = (const char*)g.w;
+    d.seg[s].in_ld_b = (long long)g.in_ld * es;
+    d.seg[s].ck_b = g.Ck * es;
+    d.seg[s].w_tap_b = (long long)a->Cout * g.Ck * es;
+    d.seg[s].R = g.R;
+    d.seg[s].dil = g.dil;
+    if (s < a->nseg && (d.seg[s].ck_b % 128) != 0) wide = false;
+  }
+  d.out = (char*)a->out; d.out_ld = a->out_ld;
+  d.bias = a->bias; d.img_bias = a->img_bias; d.stat = a->stat_partials;
+  const long long mtiles = (d.M + TILE - 1) / TILE;
+  const long long blocks = mtiles * d.n_tiles;
+  SEGK_REQUIRE(blocks < 2147483647LL, "conv: too many tiles");
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == SEGK_BF16) {
+    if (a->out_dtype == SEGK_BF16)
+      rc = wide ? launch_fwd<bf16_t, 128, bf16_t>(d, (int)blocks, st) : launch_fwd<bf16_t, 64, bf16_t>(d, (int)blocks, st);
+    else
+      rc = wide ? launch_fwd<bf16_t, 128, float>(d, (int)blocks, st) : launch_fwd<bf16_t, 64, float>(d, (int)blocks, st);
+  } else {
+    if (a->out_dtype == SEGK_BF16)
+      rc = launch_fwd<float, 128, bf16_t>(d, (int)blocks, st);
+    else
+      rc = launch_fwd<float, 128, float>(d, (int)blocks, st);
+  }
+  if (rc != SEGK_OK) return rc;
+  SEGK_CHECK_LAUNCH("conv_fwd");
+  return SEGK_OK;
+}
+
+extern "C" int segk_conv_wgrad(const segk_wgrad_args* a, segk_stream_t stream) {
+  SEGK_REQUIRE(a && a->in && a->dout && a->slabs, "wgrad: null pointer");
+  SEGK_REQUIRE(valid_dtype(a->dtype), "wgrad: bad dtype");
+  SEGK_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0, "wgrad: bad shape");
+  SEGK_REQUIRE(a->Cin > 0 && a->Cin % 32 == 0 && a->Cin <= a->in_ld, "wgrad: Cin=%d must be a multiple of 32 and <= ld=%d",
+               a->Cin, a->in_ld);
+  SEGK_REQUIRE(a->Cout > 0 && a->Cout % 16 == 0 && a->Cout <= a->dout_ld, "wgrad: Cout=%d must be a multiple of 16 and <= ld=%d",
+               a->Cout, a->dout_ld);
+  SEGK_REQUIRE((a->R == 1 || a->R == 3) && a->dil >= 1 && a->splits >= 1, "wgrad: R=%d dil=%d splits=%d", a->R, a->dil,
+               a->splits);
+  const int es = dtype_size(a->dtype);
+  SEGK_REQUIRE(aligned16(a->in) && aligned16(a->dout) && aligned16(a->slabs) && ((long long)a->in_ld * es) % 16 == 0 &&
+                   ((long long)a->dout_ld * es) % 16 == 0,
+               "wgrad: operands must be 16-byte aligned with 16-byte multiple row strides");
+  WgradDev d;
+  d.H = a->H; d.W = a->W; d.HW = a->H * a->W;
+  d.M = (long long)a->N * d.HW;
+  d.in = (const char*)a->in; d.dout = (const char*)a->dout;
+  d.in_ld_b = (long long)a->in_ld * es; d.dout_ld_b = (long long)a->dout_ld * es;
+  d.Cin = a->Cin; d.Cout = a->Cout; d.R = a->R; d.dil = a->dil; d.splits = a->splits;
+  d.co_tiles = ceil_div(a->Cout, TILE); d.ci_tiles = ceil_div(a->Cin, TILE);
+  const int bp = a->dtype == SEGK_BF16 ? WgFrag<bf16_t>::BP : WgFrag<float>::BP;
+  long long per = (d.M + a->splits - 1) / a->splits;
+  per = (per + bp - 1) / bp * bp;
+  d.per_split = per;
+  d.slabs = a->slabs;
+  const long long blocks = (long long)d.co_tiles * d.ci_tiles * a->R * a->R * a->splits;
+  SEGK_REQUIRE(blocks < 2147483647LL, "wgrad: too many tiles");
+  hipStream_t st = (hipStream_t)stream;
+  const int lds = 4 * 16384;
+  int rc;
+  if (a->dtype == SEGK_BF16) {
+    rc = set_lds(conv_wgrad_kernel<bf16_t>, lds, "conv_wgrad");
+    if (rc != SEGK_OK) return rc;
+    conv_wgrad_kernel<bf16_t><<<(int)blocks, CONV_THREADS, lds, st>>>(d);
+  } else {
+    rc = set_lds(conv_wgrad_kernel<float>, lds, "conv_wgrad");
+    if (rc != SEGK_OK) return rc;
+    conv_wgrad_kernel<float><<<(int)blocks, CONV_THREADS, lds, st>>>(d);
+  }
+  SEGK_CHECK_LAUNCH("conv_wgrad");
+  return SEGK_OK;
+}

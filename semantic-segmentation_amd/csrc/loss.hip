@@ -1,0 +1,247 @@
+// Cross-entropy with ignore index (fused log-softmax + NLL, forward and backward), class argmax and the
+// confusion-matrix histogram.  HBM-bound: logits are NCHW fp32, one thread per pixel walks the K class
+// planes, so every wavefront access is a contiguous run of one plane.
+#include <math.h>
+
+#include "common.h"
+
+namespace segk {
+
+constexpr int CE_THREADS = 256;
+constexpr int CE_MAX_ROWS = 2048;
+
+static int ce_rows(long long pixels) {
+  long long r = (pixels + CE_THREADS - 1) / CE_THREADS;
+  if (r < 1) r = 1;
+  if (r > CE_MAX_ROWS) r = CE_MAX_ROWS;
+  return (int)r;
+}
+
+__device__ __forceinline__ int label_of(float t) { return (int)(long long)t; }  // .long(): truncation
+
+__global__ __launch_bounds__(CE_THREADS) void ce_fwd_kernel(const float* __restrict__ logits,
+                                                             const float* __restrict__ target,
+                                                             const float* __restrict__ weight, int K, int HW,
+                                                             long long P, int ignore_index, float* __restrict__ lse_out,
+                                                             float* __restrict__ partials) {
+  float loss = 0.f, wsum = 0.f;
+  for (long long i = (long long)blockIdx.x * CE_THREADS + threadIdx.x; i < P; i += (long long)gridDim.x * CE_THREADS) {
+    const long long n = i / HW;
+    const int p = (int)(i - n * HW);
+    const float* l = logits + (size_t)n * K * HW + p;
+    float m = -INFINITY, s = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float v = l[(size_t)k * HW];
+      if (v > m) {
+        s = s * __expf(m - v) + 1.f;
+        m = v;
+      } else {
+        s += __expf(v - m);
+      }
+    }
+    const float lse = m + __logf(s);
+    lse_out[i] = lse;
+    const int t = label_of(target[i]);
+    if (t != ignore_index && t >= 0 && t < K) {
+      const float w = weight ? weight[t] : 1.f;
+      loss += w * (lse - l[(size_t)t * HW]);
+      wsum += w;
+    }
+  }
+  __shared__ float ra[CE_THREADS / 64], rb[CE_THREADS / 64];
+  loss = wave_sum(loss);
+  wsum = wave_sum(wsum);
+  if ((threadIdx.x & 63) == 0) {
+    ra[threadIdx.x >> 6] = loss;
+    rb[threadIdx.x >> 6] = wsum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x + 0] = (ra[0] + ra[1]) + (ra[2] + ra[3]);
+    partials[2 * blockIdx.x + 1] = (rb[0] + rb[1]) + (rb[2] + rb[3]);
+  }
+}
+
+// one block; rows are summed in a fixed order (strided per thread, then a fixed tree) in double
+__global__ __launch_bounds__(256) void ce_finish_kernel(const float* __restrict__ partials, int rows,
+                                                         float* __restrict__ sums) {
+  __shared__ double sa[256], sb[256];
+  double a = 0.0, b = 0.0;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    a += (double)partials[2 * r];
+    b += (double)partials[2 * r + 1];
+  }
+  sa[threadIdx.x] = a;
+  sb[threadIdx.x] = b;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      sa[threadIdx.x] += sa[threadIdx.x + o];
+      sb[threadIdx.x] += sb[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    sums[0] = (float)sa[0];
+    sums[1] = (float)sb[0];
+  }
+}
+
+__global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(const float* __restrict__ logits,
+                                                             const float* __restrict__ target,
+                                                             const float* __restrict__ weight,
+                                                             const float* __restrict__ lse, int K, int HW, long long P,
+                                                             int ignore_index, const float* __restrict__ coef_dev,
+                                                             float* __restrict__ dlogits) {
+  const float coef = *coef_dev;
+  for (long long i = (long long)blockIdx.x * CE_THREADS + threadIdx.x; i < P; i += (long long)gridDim.x * CE_THREADS) {
+    const long long n = i / HW;
+    const int p = (int)(i - n * HW);
+    const size_t base = (size_t)n * K * HW + p;
+    const int t = label_of(target[i]);
+    const bool valid = (t != ignore_index && t >= 0 && t < K);
+    if (!valid) {
+      for (int k = 0; k < K; ++k) dlogits[base + (size_t)k * HW] = 0.f;
+      continue;
+    }
+    const float c = coef * (weight ? weight[t] : 1.f);
+    const float e = lse[i];
+    for (int k = 0; k < K; ++k) {
+      const float sm = __expf(logits[base + (size_t)k * HW] - e);
+      dlogits[base + (size_t)k * HW] = c * (sm - (k == t ? 1.f : 0.f));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int K, int HW, long long P,
+                                                      int64_t* __restrict__ pred) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < P; i += (long long)gridDim.x * 256) {
+    const long long n = i / HW;
+    const int p = (int)(i - n * HW);
+    const float* l = logits + (size_t)n * K * HW + p;
+    float best = l[0];
+    int bi = 0;
+    for (int k = 1; k < K; ++k) {
+      const float v = l[(size_t)k * HW];
+      // first maximal index; a NaN is maximal (and the first NaN wins)
+      if (v > best || (v != v && best == best)) {
+        best = v;
+        bi = k;
+      }
+    }
+    pred[i] = bi;
+  }
+}
+
+// LDS-privatised histogram: each block counts into K*K (+1) 32-bit bins in LDS and flushes the non-zero
+// bins with one 64-bit integer atomic each (integer atomics commute, so the result is exact and
+// reproducible).  Each block sees < 2^32 pixels.
+template <bool GT_I64, bool USE_LDS>
+__global__ __launch_bounds__(256) void confmat_kernel(const void* __restrict__ gt_, const int64_t* __restrict__ pred,
+                                                       long long count, int K, unsigned long long* __restrict__ cm) {
+  extern __shared__ __attribute__((aligned(16))) unsigned int bins[];
+  const int nb = K * K + 1;
+  if (USE_LDS) {
+    for (int b = threadIdx.x; b < nb; b += 256) bins[b] = 0u;
+    __syncthreads();
+  }
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+    long long g;
+    bool ok;
+    if (GT_I64) {
+      g = ((const int64_t*)gt_)[i];
+      ok = g >= 0 && g < K;
+    } else {
+      const float f = ((const float*)gt_)[i];
+      ok = f >= 0.f && f < (float)K;
+      g = ok ? (long long)f : 0;
+    }
+    if (!ok) continue;
+    const long long pr = pred[i];
+    const int b = (pr >= 0 && pr < K) ? (int)(g * K + pr) : K * K;
+    if (USE_LDS)
+      atomicAdd(&bins[b], 1u);
+    else
+      atomicAdd(&cm[b], 1ull);
+  }
+  if (USE_LDS) {
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += 256) {
+      const unsigned int v = bins[b];
+      if (v) atomicAdd(&cm[b], (unsigned long long)v);
+    }
+  }
+}
+
+}  // namespace segk
+
+using namespace segk;
+
+extern "C" int segk_ce_partial_rows(long long pixels) { return pixels > 0 ? ce_rows(pixels) : SEGK_INVALID_ARG; }
+
+extern "C" int segk_ce_fwd(const float* logits, const float* target, const float* weight, int N, int K, int HW,
+                           int ignore_index, float* lse, float* partials, float* sums, segk_stream_t stream) {
+  SEGK_REQUIRE(logits && target && lse && partials && sums, "ce_fwd: null pointer");
+  SEGK_REQUIRE(N > 0 && K > 0 && HW > 0, "ce_fwd: bad shape N=%d K=%d HW=%d", N, K, HW);
+  const long long P = (long long)N * HW;
+  const int rows = ce_rows(P);
+  hipStream_t st = (hipStream_t)stream;
+  ce_fwd_kernel<<<rows, CE_THREADS, 0, st>>>(logits, target, weight, K, HW, P, ignore_index, lse, partials);
+  SEGK_CHECK_LAUNCH("ce_fwd");
+  ce_finish_kernel<<<1, 256, 0, st>>>(partials, rows, sums);
+  SEGK_CHECK_LAUNCH("ce_finish");
+  return SEGK_OK;
+}
+
+extern "C" int segk_ce_bwd(const float* logits, const float* target, const float* weight, const float* lse, int N,
+                           int K, int HW, int ignore_index, const float* coef_dev, float* dlogits,
+                           segk_stream_t stream) {
+  SEGK_REQUIRE(logits && target && lse && coef_dev && dlogits, "ce_bwd: null pointer");
+  SEGK_REQUIRE(N > 0 && K > 0 && HW > 0, "ce_bwd: bad shape N=%d K=%d HW=%d", N, K, HW);
+  const long long P = (long long)N * HW;
+  long long blocks = (P + CE_THREADS - 1) / CE_THREADS;
+  if (blocks > 16384) blocks = 16384;
+  ce_bwd_kernel<<<(int)blocks, CE_THREADS, 0, (hipStream_t)stream>>>(logits, target, weight, lse, K, HW, P, ignore_index,
+                                                                     coef_dev, dlogits);
+  SEGK_CHECK_LAUNCH("ce_bwd");
+  return SEGK_OK;
+}
+
+extern "C" int segk_argmax(const float* logits, int N, int K, int HW, int64_t* pred, segk_stream_t stream) {
+  SEGK_REQUIRE(logits && pred, "argmax: null pointer");
+  SEGK_REQUIRE(N > 0 && K > 0 && HW > 0, "argmax: bad shape N=%d K=%d HW=%d", N, K, HW);
+  const long long P = (long long)N * HW;
+  long long blocks = (P + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  argmax_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(logits, K, HW, P, pred);
+  SEGK_CHECK_LAUNCH("argmax");
+  return SEGK_OK;
+}
+
+extern "C" int segk_confmat(const void* gt, int gt_is_i64, const int64_t* pred, long long count, int K, int64_t* cm,
+                            segk_stream_t stream) {
+  SEGK_REQUIRE(gt && pred && cm, "confmat: null pointer");
+  SEGK_REQUIRE(count >= 0 && K > 0 && K <= 32768, "confmat: bad shape count=%lld K=%d", count, K);
+  if (count == 0) return SEGK_OK;
+  const size_t lds = ((size_t)K * K + 1) * sizeof(unsigned int);
+  const bool use_lds = lds <= 60 * 1024;
+  // each block must see fewer than 2^32 pixels; 1024 blocks of >= 16K pixels keep the flush cost small
+  long long blocks = (count + 16383) / 16384;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 1024) blocks = 1024;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* c = (unsigned long long*)cm;
+  if (use_lds) {
+    if (gt_is_i64)
+      confmat_kernel<true, true><<<(int)blocks, 256, lds, st>>>(gt, pred, count, K, c);
+    else
+      confmat_kernel<false, true><<<(int)blocks, 256, lds, st>>>(gt, pred, count, K, c);
+  } else {
+    if (gt_is_i64)
+      confmat_kernel<true, false><<<(int)blocks, 256, 0, st>>>(gt, pred, count, K, c);
+    else
+      confmat_kernel<false, false><<<(int)blocks, 256, 0, st>>>(gt, pred, count, K, c);
+  }
+  SEGK_CHECK_LAUNCH("confmat");
+  return SEGK_OK;
+}

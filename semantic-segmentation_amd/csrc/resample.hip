@@ -1,0 +1,316 @@
+// Global average pooling and align-corners bilinear resampling (forward and gather-form backward).
+// HBM-bound kernels: every output element is written once, no atomics anywhere.
+#include "common.h"
+
+namespace segk {
+
+// ------------------------------------------------------------------ pooling ----
+// Block (chunk, n): 64 channel groups of 4 channels x 4 pixel phases.
+template <typename T>
+__global__ __launch_bounds__(256) void pool_sum_kernel(const T* __restrict__ x, int ld, int HW, int C, float scale,
+                                                        float* __restrict__ out) {
+  __shared__ float red[4][256];
+  const int n = blockIdx.y;
+  const int cl = (threadIdx.x & 63) * 4;       // channel offset inside the 256-channel slab
+  const int c0 = blockIdx.x * 256 + cl;
+  const int ph = threadIdx.x >> 6;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  const T* base = x + (size_t)n * HW * ld;
+  if (c0 < C) {
+    for (int p = ph; p < HW; p += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c0 + j < C) a[j] += Elem<T>::load(base + (size_t)p * ld + c0 + j);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[ph][cl + j] = a[j];
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) {
+    const float s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    out[(size_t)n * C + c] = s * scale;
+  }
+}
+
+// --------------------------------------------------------------- resampling ----
+// Source position of output index o exactly as the framework computes it for align_corners=True:
+// scale = (in-1)/(out-1) in fp32 (0 when out == 1), position = scale*o, lower index by truncation.
+struct Tap {
+  int i0, i1;
+  float w0, w1;
+};
+
+__device__ __forceinline__ Tap source_taps(int o, float scale, int in_size) {
+  Tap t;
+  const float s = scale * (float)o;
+  int i0 = (int)s;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  float l = s - (float)i0;
+  l = l < 0.f ? 0.f : (l > 1.f ? 1.f : l);
+  t.i0 = i0;
+  t.i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  t.w1 = l;
+  t.w0 = 1.f - l;
+  return t;
+}
+
+// weight with which output index o reads input index i
+__device__ __forceinline__ float tap_weight(int o, int i, float scale, int in_size) {
+  const Tap t = source_taps(o, scale, in_size);
+  return (t.i0 == i ? t.w0 : 0.f) + (t.i1 == i ? t.w1 : 0.f);
+}
+
+// inclusive range of output indices that can read input index i (conservative; weights decide)
+__device__ __forceinline__ void reader_range(int i, float scale, int out_size, int& lo, int& hi) {
+  if (scale <= 0.f) {
+    lo = 0;
+    hi = out_size - 1;
+    return;
+  }
+  const float inv = 1.f / scale;
+  lo = (int)floorf(((float)i - 1.f) * inv) - 1;
+  hi = (int)ceilf(((float)i + 1.f) * inv) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out_size - 1) hi = out_size - 1;
+}
+
+static inline float host_scale(int in_size, int out_size) {
+  return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+}
+
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, float (&v)[4]);
+template <>
+__device__ __forceinline__ void load4<float>(const float* p, float (&v)[4]) {
+  f32x4 t = *reinterpret_cast<const f32x4*>(p);
+  v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+template <>
+__device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float (&v)[4]) {
+  u32x2 t = *reinterpret_cast<const u32x2*>(p);
+  v[0] = __uint_as_float(t[0] << 16); v[1] = __uint_as_float(t[0] & 0xffff0000u);
+  v[2] = __uint_as_float(t[1] << 16); v[3] = __uint_as_float(t[1] & 0xffff0000u);
+}
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const float (&v)[4]);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, const float (&v)[4]) {
+  f32x4 t = {v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(p) = t;
+}
+template <>
+__device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float (&v)[4]) {
+  u32x2 t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+  *reinterpret_cast<u32x2*>(p) = t;
+}
+
+// pixel-major -> pixel-major; thread = (output pixel, group of 4 channels); C % 4 == 0
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void upsample_fwd_pm_kernel(const TI* __restrict__ in, int in_ld, int C, int Hi, int Wi,
+                                                               TO* __restrict__ out, int out_ld, int Ho, int Wo,
+                                                               float sy, float sx, long long total) {
+  const int cg = C >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long pix = i / cg;
+    const int c0 = (int)(i - pix * cg) * 4;
+    const int ox = (int)(pix % Wo);
+    const long long t = pix / Wo;
+    const int oy = (int)(t % Ho);
+    const long long n = t / Ho;
+    const Tap ty = source_taps(oy, sy, Hi), tx = source_taps(ox, sx, Wi);
+    const TI* b = in + (size_t)n * Hi * Wi * in_ld + c0;
+    float v00[4], v01[4], v10[4], v11[4], o[4];
+    load4<TI>(b + ((size_t)ty.i0 * Wi + tx.i0) * in_ld, v00);
+    load4<TI>(b + ((size_t)ty.i0 * Wi + tx.i1) * in_ld, v01);
+    load4<TI>(b + ((size_t)ty.i1 * Wi + tx.i0) * in_ld, v10);
+    load4<TI>(b + ((size_t)ty.i1 * Wi + tx.i1) * in_ld, v11);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = ty.w0 * (tx.w0 * v00[j] + tx.w1 * v01[j]) + ty.w1 * (tx.w0 * v10[j] + tx.w1 * v11[j]);
+    store4<TO>(out + (size_t)pix * out_ld + c0, o);
+  }
+}
+
+// pixel-major -> NCHW fp32; thread = output pixel (x fastest => coalesced plane writes)
+template <typename TI>
+__global__ __launch_bounds__(256) void upsample_fwd_nchw_kernel(const TI* __restrict__ in, int in_ld, int C, int Hi,
+                                                                 int Wi, float* __restrict__ out, int Ho, int Wo,
+                                                                 float sy, float sx) {
+  const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int n = blockIdx.z;
+  if (ox >= Wo || oy >= Ho) return;
+  const Tap ty = source_taps(oy, sy, Hi), tx = source_taps(ox, sx, Wi);
+  const TI* b = in + (size_t)n * Hi * Wi * in_ld;
+  const TI* p00 = b + ((size_t)ty.i0 * Wi + tx.i0) * in_ld;
+  const TI* p01 = b + ((size_t)ty.i0 * Wi + tx.i1) * in_ld;
+  const TI* p10 = b + ((size_t)ty.i1 * Wi + tx.i0) * in_ld;
+  const TI* p11 = b + ((size_t)ty.i1 * Wi + tx.i1) * in_ld;
+  const size_t plane = (size_t)Ho * Wo;
+  float* o = out + (size_t)n * C * plane + (size_t)oy * Wo + ox;
+  for (int c0 = 0; c0 < C; c0 += 4) {
+    float v00[4], v01[4], v10[4], v11[4];
+    load4<TI>(p00 + c0, v00);
+    load4<TI>(p01 + c0, v01);
+    load4<TI>(p10 + c0, v10);
+    load4<TI>(p11 + c0, v11);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c0 + j < C)
+        o[(size_t)(c0 + j) * plane] =
+            ty.w0 * (tx.w0 * v00[j] + tx.w1 * v01[j]) + ty.w1 * (tx.w0 * v10[j] + tx.w1 * v11[j]);
+  }
+}
+
+// gradient, pixel-major dout -> pixel-major din; thread = (input pixel, group of 4 channels)
+template <typename TG>
+__global__ __launch_bounds__(256) void upsample_bwd_pm_kernel(const TG* __restrict__ dout, int dout_ld, int C, int Ho,
+                                                               int Wo, TG* __restrict__ din, int din_ld, int cpad,
+                                                               int Hi, int Wi, float sy, float sx, long long total) {
+  const int cg = cpad >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long pix = i / cg;
+    const int c0 = (int)(i - pix * cg) * 4;
+    const int ix = (int)(pix % Wi);
+    const long long t = pix / Wi;
+    const int iy = (int)(t % Hi);
+    const long long n = t / Hi;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < C) {
+      int ylo, yhi, xlo, xhi;
+      reader_range(iy, sy, Ho, ylo, yhi);
+      reader_range(ix, sx, Wo, xlo, xhi);
+      const TG* b = dout + (size_t)n * Ho * Wo * dout_ld + c0;
+      for (int oy = ylo; oy <= yhi; ++oy) {
+        const float wy = tap_weight(oy, iy, sy, Hi);
+        if (wy == 0.f) continue;
+        for (int ox = xlo; ox <= xhi; ++ox) {
+          const float w = wy * tap_weight(ox, ix, sx, Wi);
+          if (w == 0.f) continue;
+          float g[4];
+          load4<TG>(b + ((size_t)oy * Wo + ox) * dout_ld, g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = fmaf(w, g[j], acc[j]);
+        }
+      }
+    }
+    store4<TG>(din + (size_t)pix * din_ld + c0, acc);
+  }
+}
+
+// gradient, NCHW fp32 dout -> pixel-major din; thread = (input pixel, channel), x fastest
+template <typename TG>
+__global__ __launch_bounds__(256) void upsample_bwd_nchw_kernel(const float* __restrict__ dout, int C, int Ho, int Wo,
+                                                                 TG* __restrict__ din, int din_ld, int cpad, int Hi,
+                                                                 int Wi, float sy, float sx) {
+  const int ix = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int iy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int n = blockIdx.z / cpad;
+  const int c = blockIdx.z % cpad;
+  if (ix >= Wi || iy >= Hi) return;
+  float acc = 0.f;
+  if (c < C) {
+    int ylo, yhi, xlo, xhi;
+    reader_range(iy, sy, Ho, ylo, yhi);
+    reader_range(ix, sx, Wo, xlo, xhi);
+    const float* b = dout + ((size_t)n * C + c) * Ho * Wo;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const float wy = tap_weight(oy, iy, sy, Hi);
+      if (wy == 0.f) continue;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        const float w = wy * tap_weight(ox, ix, sx, Wi);
+        if (w != 0.f) acc = fmaf(w, b[(size_t)oy * Wo + ox], acc);
+      }
+    }
+  }
+  Elem<TG>::store(din + (((size_t)n * Hi + iy) * Wi + ix) * din_ld + c, acc);
+}
+
+static bool aligned_to(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
+
+}  // namespace segk
+
+using namespace segk;
+
+extern "C" int segk_pool_sum(const void* x, int dtype, int ld, int N, int HW, int C, float scale, float* out,
+                             segk_stream_t stream) {
+  SEGK_REQUIRE(x && out && valid_dtype(dtype), "pool_sum: null pointer or bad dtype");
+  SEGK_REQUIRE(N > 0 && N <= 65535 && HW > 0 && C > 0 && ld >= C, "pool_sum: bad shape N=%d HW=%d C=%d ld=%d", N, HW, C,
+               ld);
+  dim3 grid(ceil_div(C, 256), N);
+  hipStream_t st = (hipStream_t)stream;
+  SEGK_DISPATCH_DTYPE(dtype, T, (pool_sum_kernel<T><<<grid, 256, 0, st>>>((const T*)x, ld, HW, C, scale, out)));
+  SEGK_CHECK_LAUNCH("pool_sum");
+  return SEGK_OK;
+}
+
+extern "C" int segk_upsample_fwd(const void* in, int in_dtype, int in_ld, int N, int C, int Hi, int Wi, void* out,
+                                 int out_dtype, int out_layout, int out_ld, int Ho, int Wo, segk_stream_t stream) {
+  SEGK_REQUIRE(in && out && valid_dtype(in_dtype) && valid_dtype(out_dtype), "upsample_fwd: null pointer or bad dtype");
+  SEGK_REQUIRE(N > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "upsample_fwd: bad shape");
+  SEGK_REQUIRE(in_ld % 4 == 0 && in_ld >= round_up(C, 4) && aligned_to(in, in_dtype == SEGK_BF16 ? 8 : 16),
+               "upsample_fwd: source needs ld %% 4 == 0, ld >= C rounded up to 4, 4-element aligned base (ld=%d C=%d)",
+               in_ld, C);
+  const float sy = host_scale(Hi, Ho), sx = host_scale(Wi, Wo);
+  hipStream_t st = (hipStream_t)stream;
+  if (out_layout == SEGK_PM) {
+    SEGK_REQUIRE(C % 4 == 0 && out_ld % 4 == 0 && out_ld >= C && aligned_to(out, out_dtype == SEGK_BF16 ? 8 : 16),
+                 "upsample_fwd: pixel-major destination needs C %% 4 == 0 and 4-element alignment (C=%d ld=%d)", C,
+                 out_ld);
+    const long long total = (long long)N * Ho * Wo * (C / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+#define LAUNCH_UP(TI, TO)                                                                                         \
+  upsample_fwd_pm_kernel<TI, TO><<<(int)blocks, 256, 0, st>>>((const TI*)in, in_ld, C, Hi, Wi, (TO*)out, out_ld, Ho, \
+                                                              Wo, sy, sx, total)
+    if (in_dtype == SEGK_BF16 && out_dtype == SEGK_BF16) { LAUNCH_UP(bf16_t, bf16_t); }
+    else if (in_dtype == SEGK_BF16) { LAUNCH_UP(bf16_t, float); }
+    else if (out_dtype == SEGK_BF16) { LAUNCH_UP(float, bf16_t); }
+    else { LAUNCH_UP(float, float); }
+#undef LAUNCH_UP
+  } else if (out_layout == SEGK_NCHW) {
+    SEGK_REQUIRE(out_dtype == SEGK_F32, "upsample_fwd: the NCHW destination is fp32");
+    SEGK_REQUIRE(N <= 65535 && ceil_div(Ho, 4) <= 65535, "upsample_fwd: grid too large");
+    dim3 grid(ceil_div(Wo, 64), ceil_div(Ho, 4), N);
+    SEGK_DISPATCH_DTYPE(in_dtype, T, (upsample_fwd_nchw_kernel<T><<<grid, 256, 0, st>>>((const T*)in, in_ld, C, Hi, Wi,
+                                                                                        (float*)out, Ho, Wo, sy, sx)));
+  } else {
+    SEGK_REQUIRE(false, "upsample_fwd: bad layout %d", out_layout);
+  }
+  SEGK_CHECK_LAUNCH("upsample_fwd");
+  return SEGK_OK;
+}
+
+extern "C" int segk_upsample_bwd(const void* dout, int dout_dtype, int dout_layout, int dout_ld, int N, int C, int Ho,
+                                 int Wo, void* din, int din_dtype, int din_ld, int din_cpad, int Hi, int Wi,
+                                 segk_stream_t stream) {
+  SEGK_REQUIRE(dout && din && valid_dtype(dout_dtype) && valid_dtype(din_dtype), "upsample_bwd: null pointer or bad dtype");
+  SEGK_REQUIRE(N > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && din_cpad >= C && din_ld >= din_cpad,
+               "upsample_bwd: bad shape C=%d cpad=%d ld=%d", C, din_cpad, din_ld);
+  const float sy = host_scale(Hi, Ho), sx = host_scale(Wi, Wo);
+  hipStream_t st = (hipStream_t)stream;
+  if (dout_layout == SEGK_PM) {
+    SEGK_REQUIRE(dout_dtype == din_dtype, "upsample_bwd: pixel-major gradient keeps its dtype");
+    SEGK_REQUIRE(C % 4 == 0 && din_cpad % 4 == 0 && dout_ld % 4 == 0 && din_ld % 4 == 0 && dout_ld >= C &&
+                     aligned_to(dout, dout_dtype == SEGK_BF16 ? 8 : 16) && aligned_to(din, din_dtype == SEGK_BF16 ? 8 : 16),
+                 "upsample_bwd: pixel-major form needs C %% 4 == 0 and 4-element alignment");
+    const long long total = (long long)N * Hi * Wi * (din_cpad / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    SEGK_DISPATCH_DTYPE(dout_dtype, T,
+                        (upsample_bwd_pm_kernel<T><<<(int)blocks, 256, 0, st>>>((const T*)dout, dout_ld, C, Ho, Wo, (T*)din,
+                                                                               din_ld, din_cpad, Hi, Wi, sy, sx, total)));
+  } else if (dout_layout == SEGK_NCHW) {
+    SEGK_REQUIRE(dout_dtype == SEGK_F32, "upsample_bwd: the NCHW gradient is fp32");
+    SEGK_REQUIRE((long long)N * din_cpad <= 65535 && ceil_div(Hi, 4) <= 65535, "upsample_bwd: grid too large");
+    dim3 grid(ceil_div(Wi, 64), ceil_div(Hi, 4), N * din_cpad);
+    SEGK_DISPATCH_DTYPE(din_dtype, T, (upsample_bwd_nchw_kernel<T><<<grid, 256, 0, st>>>((const float*)dout, C, Ho, Wo,
+                                                                                         (T*)din, din_ld, din_cpad, Hi,
+                                                                                         Wi, sy, sx)));
+  } else {
+    SEGK_REQUIRE(false, "upsample_bwd: bad layout %d", dout_layout);
+  }
+  SEGK_CHECK_LAUNCH("upsample_bwd");
+  return SEGK_OK;
+}

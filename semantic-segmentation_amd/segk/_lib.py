@@ -1,0 +1,108 @@
+"""ctypes binding of libsegk.so (the C ABI declared in include/segk.h).
+
+There is no fallback: if the shared library is missing or a call fails, the
+caller gets an exception.  The library is built in-tree by
+``__graft_entry__.build()`` / ``make -C semantic-segmentation_amd/csrc``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsegk.so")
+
+F32, BF16 = 0, 1
+PM, NCHW = 0, 1
+MAX_SEG = 4
+
+c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
+
+
+class ConvSeg(ctypes.Structure):
+    _fields_ = [("inp", c_void_p), ("w", c_void_p), ("in_ld", c_int), ("Ck", c_int), ("R", c_int), ("dil", c_int)]
+
+
+class ConvArgs(ctypes.Structure):
+    _fields_ = [("N", c_int), ("H", c_int), ("W", c_int), ("dtype", c_int), ("Cout", c_int), ("nseg", c_int),
+                ("seg", ConvSeg * MAX_SEG), ("out", c_void_p), ("out_ld", c_int), ("out_dtype", c_int),
+                ("bias", c_void_p), ("img_bias", c_void_p), ("stat_partials", c_void_p)]
+
+
+class WgradArgs(ctypes.Structure):
+    _fields_ = [("N", c_int), ("H", c_int), ("W", c_int), ("dtype", c_int), ("inp", c_void_p), ("in_ld", c_int),
+                ("Cin", c_int), ("dout", c_void_p), ("dout_ld", c_int), ("Cout", c_int), ("R", c_int),
+                ("dil", c_int), ("splits", c_int), ("slabs", c_void_p)]
+
+
+# name -> argument types (every function returns int unless listed in _RESTYPES)
+SIGNATURES = {
+    "segk_version": [],
+    "segk_last_error": [],
+    "segk_device_count": [],
+    "segk_nchw_to_pm": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "segk_pm_to_nchw": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "segk_pack_weight": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "segk_conv_fwd": [ctypes.POINTER(ConvArgs), c_void_p],
+    "segk_conv_stat_rows": [ctypes.POINTER(ConvArgs)],
+    "segk_conv_wgrad": [ctypes.POINTER(WgradArgs), c_void_p],
+    "segk_wgrad_finish": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
+    "segk_bn_stats": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "segk_bn_stat_rows": [c_int, c_int, c_int, c_int],
+    "segk_bn_reduce": [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p],
+    "segk_bn_coeffs": [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p,
+                       c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "segk_bn_coeffs_eval": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                            c_void_p, c_int, c_void_p],
+    "segk_bn_apply": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                      c_void_p, c_int, c_void_p, c_float, c_void_p],
+    "segk_bn_bwd_stats": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                          c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p],
+    "segk_bn_bwd_apply": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                          c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float,
+                          c_void_p, c_int, c_void_p],
+    "segk_pool_sum": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p],
+    "segk_upsample_fwd": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                          c_int, c_void_p],
+    "segk_upsample_bwd": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                          c_int, c_int, c_void_p],
+    "segk_ce_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                    c_void_p],
+    "segk_ce_partial_rows": [c_ll],
+    "segk_ce_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                    c_void_p],
+    "segk_argmax": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "segk_confmat": [c_void_p, c_int, c_void_p, c_ll, c_int, c_void_p, c_void_p],
+}
+_RESTYPES = {"segk_last_error": ctypes.c_char_p}
+
+_lib = None
+
+
+class SegkError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libsegk.so once and attach the prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SegkError("libsegk.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "or `make -C semantic-segmentation_amd/csrc`" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an entry point; a negative status becomes SegkError with the library's message."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc < 0:
+        msg = lib.segk_last_error()
+        raise SegkError("%s failed (%d): %s" % (name, rc, msg.decode("utf-8", "replace") if msg else ""))
+    return rc

@@ -1,0 +1,351 @@
+"""Tensor-level wrappers over the C ABI: argument checks, workspace allocation, one call each.
+
+Pixel-major activations are 2-D torch views ``[M, C]`` with strides ``(ld, 1)`` (so a channel
+slice of a wider concat buffer is just ``buf[:, a:b]``).  Everything here requires CUDA/HIP
+tensors; nothing computes on the host.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, NCHW, PM, ConvArgs, WgradArgs, call
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError("segk supports float32 and bfloat16 tensors, got %s" % (t.dtype,))
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise ValueError("segk kernels need tensors on the GPU (got a %s tensor)" % t.device.type)
+
+
+def _pm(t):
+    """(ld, C) of a pixel-major view."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError("pixel-major view must be 2-D with unit channel stride, got shape %s strides %s"
+                         % (tuple(t.shape), t.stride()))
+    return t.stride(0), t.shape[1]
+
+
+def round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+# ------------------------------------------------------------------ layout ----
+def nchw_to_pm(x, out):
+    """x: [N,C,H,W] float32 contiguous -> out: pixel-major view [N*H*W, C]."""
+    _dev(x, out)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("nchw_to_pm expects a contiguous float32 NCHW tensor")
+    N, C, H, W = x.shape
+    ld, c = _pm(out)
+    if c != C or out.shape[0] != N * H * W:
+        raise ValueError("destination shape %s does not match %s" % (tuple(out.shape), tuple(x.shape)))
+    call("segk_nchw_to_pm", _ptr(x), _ptr(out), _dt(out), N, C, H, W, ld, _stream())
+    return out
+
+
+def pm_to_nchw(src, N, H, W):
+    _dev(src)
+    ld, C = _pm(src)
+    out = torch.empty((N, C, H, W), dtype=torch.float32, device=src.device)
+    call("segk_pm_to_nchw", _ptr(src), _dt(src), ld, _ptr(out), N, C, H, W, _stream())
+    return out
+
+
+def pack_weight(w, dtype, transpose=False):
+    """nn.Conv2d weight [Cout,Cin,R,R] fp32 -> [taps, rows, Ck] operand (see segk_pack_weight)."""
+    _dev(w)
+    if w.dtype != torch.float32:
+        raise ValueError("master weights are float32")
+    w = w.contiguous()
+    Cout, Cin, R, S = w.shape
+    if R != S:
+        raise ValueError("square kernels only")
+    rows, k = (Cin, Cout) if transpose else (Cout, Cin)
+    out = torch.empty((R * R, rows, round_up(k, 32)), dtype=dtype, device=w.device)
+    call("segk_pack_weight", _ptr(w), _ptr(out), _dt(out), Cout, Cin, R, 1 if transpose else 0, _stream())
+    return out
+
+
+# -------------------------------------------------------------------- conv ----
+def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=False):
+    """segs: list of (in_view [M, >=Ck], packed_w [taps, Cout, Ck], R, dil).  Writes `out` ([M, Cout'] view,
+    Cout' >= Cout rounded up to 4).  Returns the [rows, 2, Cout] statistic partials when want_stats."""
+    M = N * H * W
+    a = ConvArgs()
+    a.N, a.H, a.W, a.Cout, a.nseg = N, H, W, Cout, len(segs)
+    if not 1 <= len(segs) <= _lib.MAX_SEG:
+        raise ValueError("1..%d segments" % _lib.MAX_SEG)
+    dt = None
+    for i, (x, w, R, dil) in enumerate(segs):
+        _dev(x, w)
+        ld, _ = _pm(x)
+        if x.shape[0] != M:
+            raise ValueError("segment %d has %d pixels, expected %d" % (i, x.shape[0], M))
+        if w.dim() != 3 or not w.is_contiguous() or w.shape[0] != R * R or w.shape[1] != Cout:
+            raise ValueError("segment %d: packed weight shape %s does not match taps=%d Cout=%d"
+                             % (i, tuple(w.shape), R * R, Cout))
+        if x.dtype != w.dtype or (dt is not None and x.dtype != dt):
+            raise ValueError("all conv operands share one dtype")
+        dt = x.dtype
+        Ck = w.shape[2]
+        if x.shape[1] < Ck and ld < Ck:
+            raise ValueError("segment %d: activation row has %d elements, weight contracts %d" % (i, ld, Ck))
+        a.seg[i].inp, a.seg[i].w = x.data_ptr(), w.data_ptr()
+        a.seg[i].in_ld, a.seg[i].Ck, a.seg[i].R, a.seg[i].dil = ld, Ck, R, dil
+    _dev(out, bias, img_bias)
+    old, oc = _pm(out)
+    if out.shape[0] != M:
+        raise ValueError("output has %d pixels, expected %d" % (out.shape[0], M))
+    a.dtype = _dt(segs[0][0])
+    a.out, a.out_ld, a.out_dtype = out.data_ptr(), old, _dt(out)
+    for name, v, n in (("bias", bias, Cout), ("img_bias", img_bias, N * Cout)):
+        if v is not None and (v.dtype != torch.float32 or not v.is_contiguous() or v.numel() != n):
+            raise ValueError("%s must be contiguous float32 with %d elements" % (name, n))
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.img_bias = img_bias.data_ptr() if img_bias is not None else None
+    stats = None
+    if want_stats:
+        rows = call("segk_conv_stat_rows", ctypes.byref(a))
+        stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=out.device)
+        a.stat_partials = stats.data_ptr()
+    else:
+        a.stat_partials = None
+    call("segk_conv_fwd", ctypes.byref(a), _stream())
+    return stats
+
+
+def default_splits(M, Cin, Cout, R, dtype):
+    tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128) * R * R
+    bp = 64 if dtype == torch.bfloat16 else 32
+    chunks = max(1, (M + bp - 1) // bp)
+    s = max(1, min(1024 // tiles if tiles <= 1024 else 1, 64, chunks // 8 if chunks >= 8 else 1))
+    return s
+
+
+def conv_wgrad(x, dout, N, H, W, R, dil, Cout_true, Cin_true, splits=None):
+    """Weight gradient [Cout_true, Cin_true, R, R] fp32 from the forward input view x [M, Cin_pad] and the
+    output gradient view dout [M, Cout_pad] (padded channels must hold zeros)."""
+    _dev(x, dout)
+    M = N * H * W
+    in_ld, Cin = _pm(x)
+    do_ld, Cout = _pm(dout)
+    if x.shape[0] != M or dout.shape[0] != M or x.dtype != dout.dtype:
+        raise ValueError("wgrad operands disagree: %s %s M=%d" % (tuple(x.shape), tuple(dout.shape), M))
+    if splits is None:
+        splits = default_splits(M, Cin, Cout, R, x.dtype)
+    slabs = torch.empty((splits, R * R, Cin, Cout), dtype=torch.float32, device=x.device)
+    a = WgradArgs()
+    a.N, a.H, a.W, a.dtype = N, H, W, _dt(x)
+    a.inp, a.in_ld, a.Cin = x.data_ptr(), in_ld, Cin
+    a.dout, a.dout_ld, a.Cout = dout.data_ptr(), do_ld, Cout
+    a.R, a.dil, a.splits, a.slabs = R, dil, splits, slabs.data_ptr()
+    call("segk_conv_wgrad", ctypes.byref(a), _stream())
+    dw = torch.empty((Cout_true, Cin_true, R, R), dtype=torch.float32, device=x.device)
+    call("segk_wgrad_finish", _ptr(slabs), splits, R, Cin, Cout, _ptr(dw), Cout_true, Cin_true, _stream())
+    return dw
+
+
+# ---------------------------------------------------------------------- BN ----
+def _bn_geom(x, layout):
+    if layout == PM:
+        ld, C = _pm(x)
+        return 1, C, x.shape[0], ld  # N folded into the pixel count
+    if x.dim() < 2 or not x.is_contiguous():
+        raise ValueError("NCHW batch-norm input must be contiguous")
+    N, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * C) if N * C else 0
+    return N, C, HW, 0
+
+
+def bn_local_sums(x, layout):
+    """[2C+1] float32: per-channel sum, sum of squares, element count of THIS rank's tensor."""
+    _dev(x)
+    N, C, HW, ld = _bn_geom(x, layout)
+    rows = call("segk_bn_stat_rows", layout, N, C, HW)
+    partials = torch.empty((rows, 2, C), dtype=torch.float32, device=x.device)
+    call("segk_bn_stats", _ptr(x), _dt(x), layout, N, C, HW, ld, _ptr(partials), _stream())
+    return bn_reduce(partials, float(N * HW))
+
+
+def bn_reduce(partials, count):
+    rows, two, C = partials.shape
+    sums = torch.empty((2 * C + 1,), dtype=torch.float32, device=partials.device)
+    call("segk_bn_reduce", _ptr(partials), rows, C, ctypes.c_float(count), _ptr(sums), _stream())
+    return sums
+
+
+def bn_coeffs(sums, gamma, beta, eps, momentum, running_mean, running_var, legacy_clamp=False):
+    """-> coef [4, C] float32 rows: mean, inv_std, scale, shift; running statistics updated in place."""
+    C = (sums.numel() - 1) // 2
+    coef = torch.empty((4, C), dtype=torch.float32, device=sums.device)
+    _dev(sums, gamma, beta, running_mean, running_var)
+    call("segk_bn_coeffs", _ptr(sums), _ptr(gamma), _ptr(beta), ctypes.c_float(eps), ctypes.c_float(momentum),
+         1 if legacy_clamp else 0, _ptr(running_mean), _ptr(running_var), _ptr(coef[0]), _ptr(coef[1]),
+         _ptr(coef[2]), _ptr(coef[3]), C, _stream())
+    return coef
+
+
+def bn_coeffs_eval(running_mean, running_var, gamma, beta, eps):
+    C = running_mean.numel()
+    _dev(running_mean, running_var, gamma, beta)
+    coef = torch.empty((4, C), dtype=torch.float32, device=running_mean.device)
+    call("segk_bn_coeffs_eval", _ptr(running_mean), _ptr(running_var), _ptr(gamma), _ptr(beta),
+         ctypes.c_float(eps), _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]), _ptr(coef[3]), C, _stream())
+    return coef
+
+
+def _mask_check(mask, x):
+    if mask is None:
+        return
+    if mask.dtype != torch.uint8 or not mask.is_contiguous() or mask.numel() != x.numel():
+        raise ValueError("dropout mask must be a contiguous uint8 tensor with one byte per element")
+    _dev(mask)
+
+
+def bn_apply(x, y, coef, layout, relu, mask=None, mask_scale=1.0):
+    _dev(x, y, coef)
+    N, C, HW, x_ld = _bn_geom(x, layout)
+    y_ld = _pm(y)[0] if layout == PM else 0
+    if y.shape != x.shape:
+        raise ValueError("bn_apply output shape %s != input shape %s" % (tuple(y.shape), tuple(x.shape)))
+    _mask_check(mask, x)
+    call("segk_bn_apply", _ptr(x), _dt(x), x_ld, _ptr(y), _dt(y), y_ld, layout, N, C, HW, _ptr(coef[2]),
+         _ptr(coef[3]), 1 if relu else 0, _ptr(mask), ctypes.c_float(mask_scale), _stream())
+    return y
+
+
+def bn_bwd_local_sums(dz, x, coef, layout, relu, mask=None, mask_scale=1.0):
+    """[2C+1] float32: sum g, sum g*xhat, count for this rank (g = dz through dropout and ReLU)."""
+    _dev(dz, x, coef)
+    N, C, HW, x_ld = _bn_geom(x, layout)
+    dz_ld = _pm(dz)[0] if layout == PM else 0
+    if layout == NCHW and not dz.is_contiguous():
+        raise ValueError("NCHW gradient must be contiguous")
+    _mask_check(mask, x)
+    rows = call("segk_bn_stat_rows", layout, N, C, HW)
+    partials = torch.empty((rows, 2, C), dtype=torch.float32, device=x.device)
+    call("segk_bn_bwd_stats", _ptr(dz), _dt(dz), dz_ld, _ptr(x), _dt(x), x_ld, layout, N, C, HW, _ptr(coef[0]),
+         _ptr(coef[1]), _ptr(coef[2]), _ptr(coef[3]), 1 if relu else 0, _ptr(mask), ctypes.c_float(mask_scale),
+         _ptr(partials), _stream())
+    return bn_reduce(partials, float(N * HW))
+
+
+def bn_bwd_apply(dz, x, dx, coef, gsums, layout, relu, mask=None, mask_scale=1.0, eval_mode=False):
+    _dev(dz, x, dx, coef, gsums)
+    N, C, HW, x_ld = _bn_geom(x, layout)
+    dz_ld = _pm(dz)[0] if layout == PM else 0
+    dx_ld = _pm(dx)[0] if layout == PM else 0
+    _mask_check(mask, x)
+    call("segk_bn_bwd_apply", _ptr(dz), _dt(dz), dz_ld, _ptr(x), _dt(x), x_ld, _ptr(dx), _dt(dx), dx_ld, layout, N,
+         C, HW, _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]), _ptr(coef[3]), 1 if relu else 0, _ptr(mask),
+         ctypes.c_float(mask_scale), _ptr(gsums), 1 if eval_mode else 0, _stream())
+    return dx
+
+
+# ------------------------------------------------------- pooling / resample ----
+def pool_sum(x, N, HW, scale):
+    """x: pixel-major view [N*HW, C] -> [N, C] float32 = scale * sum over the pixels of each image."""
+    _dev(x)
+    ld, C = _pm(x)
+    out = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    call("segk_pool_sum", _ptr(x), _dt(x), ld, N, HW, C, ctypes.c_float(scale), _ptr(out), _stream())
+    return out
+
+
+def upsample_fwd(src, N, C, Hi, Wi, dst, Ho, Wo, dst_layout=PM):
+    """src: pixel-major [N*Hi*Wi, >=C]; dst: pixel-major view [N*Ho*Wo, C] or NCHW float32 [N,C,Ho,Wo]."""
+    _dev(src, dst)
+    ld = _pm(src)[0]
+    if dst_layout == PM:
+        out_ld = _pm(dst)[0]
+    else:
+        out_ld = 0
+        if tuple(dst.shape) != (N, C, Ho, Wo) or not dst.is_contiguous():
+            raise ValueError("NCHW destination must be contiguous [N,C,Ho,Wo]")
+    call("segk_upsample_fwd", _ptr(src), _dt(src), ld, N, C, Hi, Wi, _ptr(dst), _dt(dst), dst_layout, out_ld, Ho, Wo,
+         _stream())
+    return dst
+
+
+def upsample_bwd(dout, dout_layout, N, C, Ho, Wo, din, cpad, Hi, Wi):
+    """din: pixel-major view [N*Hi*Wi, cpad]; channels C..cpad are zero-filled."""
+    _dev(dout, din)
+    dout_ld = _pm(dout)[0] if dout_layout == PM else 0
+    if dout_layout == NCHW and not dout.is_contiguous():
+        raise ValueError("NCHW gradient must be contiguous")
+    din_ld = _pm(din)[0]
+    call("segk_upsample_bwd", _ptr(dout), _dt(dout), dout_layout, dout_ld, N, C, Ho, Wo, _ptr(din), _dt(din), din_ld,
+         cpad, Hi, Wi, _stream())
+    return din
+
+
+# -------------------------------------------------------------------- loss ----
+def ce_fwd(logits, target, weight, ignore_index):
+    """-> (sums [2] = {sum w*nll, sum w}, lse [N,H,W]) on device; logits NCHW float32, target float32."""
+    _dev(logits, target, weight)
+    if logits.dtype != torch.float32 or not logits.is_contiguous():
+        raise ValueError("logits must be contiguous float32 NCHW")
+    N, K, H, W = logits.shape
+    if target.dtype != torch.float32 or not target.is_contiguous() or target.numel() != N * H * W:
+        raise ValueError("target must be contiguous float32 [N,H,W]")
+    if weight is not None and (weight.dtype != torch.float32 or weight.numel() != K):
+        raise ValueError("class weight must be float32 [K]")
+    rows = call("segk_ce_partial_rows", N * H * W)
+    partials = torch.empty((rows, 2), dtype=torch.float32, device=logits.device)
+    lse = torch.empty((N, H, W), dtype=torch.float32, device=logits.device)
+    sums = torch.empty((2,), dtype=torch.float32, device=logits.device)
+    call("segk_ce_fwd", _ptr(logits), _ptr(target), _ptr(weight), N, K, H * W, ignore_index, _ptr(lse),
+         _ptr(partials), _ptr(sums), _stream())
+    return sums, lse
+
+
+def ce_bwd(logits, target, weight, lse, ignore_index, coef):
+    """coef: 0-dim/1-element float32 device tensor = grad_out / (sum w * batch)."""
+    _dev(logits, target, weight, lse, coef)
+    N, K, H, W = logits.shape
+    dl = torch.empty_like(logits)
+    call("segk_ce_bwd", _ptr(logits), _ptr(target), _ptr(weight), _ptr(lse), N, K, H * W, ignore_index, _ptr(coef),
+         _ptr(dl), _stream())
+    return dl
+
+
+def argmax(logits):
+    _dev(logits)
+    if logits.dtype != torch.float32 or not logits.is_contiguous() or logits.dim() != 4:
+        raise ValueError("logits must be contiguous float32 NCHW")
+    N, K, H, W = logits.shape
+    pred = torch.empty((N, H, W), dtype=torch.int64, device=logits.device)
+    call("segk_argmax", _ptr(logits), N, K, H * W, _ptr(pred), _stream())
+    return pred
+
+
+def confmat_accumulate(gt, pred, K, cm):
+    """cm: int64 [K*K+1] device accumulator (last slot: predictions outside [0,K))."""
+    _dev(gt, pred, cm)
+    if gt.dtype not in (torch.float32, torch.int64) or pred.dtype != torch.int64:
+        raise ValueError("gt must be float32 or int64 and pred int64")
+    if gt.numel() != pred.numel():
+        raise ValueError("gt and pred sizes differ")
+    if cm.dtype != torch.int64 or cm.numel() != K * K + 1 or not cm.is_contiguous():
+        raise ValueError("cm must be contiguous int64 [K*K+1]")
+    gt, pred = gt.contiguous(), pred.contiguous()
+    call("segk_confmat", _ptr(gt), 1 if gt.dtype == torch.int64 else 0, _ptr(pred), gt.numel(), K, _ptr(cm),
+         _stream())
+    return cm

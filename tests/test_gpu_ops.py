@@ -1,0 +1,379 @@
+"""Kernel-level parity on a real MI355X: each C-ABI entry point against the same op in PyTorch
+(fp32 reference on the GPU, or numpy for the integer work)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gen, ops_ref  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from segk import ops as o
+    return o
+
+
+DEV = "cuda"
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def to_pm(x, dtype, ld=None):
+    """NCHW torch tensor -> pixel-major view [M, C] inside a zero buffer with leading dimension ld."""
+    N, C, H, W = x.shape
+    ld = ld or C
+    buf = torch.zeros((N * H * W, ld), dtype=dtype, device=x.device)
+    buf[:, :C] = x.permute(0, 2, 3, 1).reshape(-1, C).to(dtype)
+    return buf[:, :C] if ld != C else buf, buf
+
+
+def from_pm(v, N, H, W):
+    return v.float().reshape(N, H, W, -1).permute(0, 3, 1, 2).contiguous()
+
+
+def relerr(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+# ------------------------------------------------------------------ layout ----
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layout_roundtrip(ops, dtype):
+    x = T(gen.normal(1, "lay", (3, 37, 5, 13)))
+    buf = torch.zeros((3 * 5 * 13, 64), dtype=dtype, device=DEV)
+    view = buf[:, 8:45]
+    ops.nchw_to_pm(x, view)
+    want = x.permute(0, 2, 3, 1).reshape(-1, 37).to(dtype)
+    assert torch.equal(view, want)
+    assert float(buf[:, :8].abs().sum()) == 0 and float(buf[:, 45:].abs().sum()) == 0
+    back = ops.pm_to_nchw(view, 3, 5, 13)
+    assert torch.equal(back, want.float().reshape(3, 5, 13, 37).permute(0, 3, 1, 2))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pack_weight(ops, dtype):
+    w = T(gen.normal(1, "pw", (21, 40, 3, 3)))
+    p = ops.pack_weight(w, dtype, transpose=False)
+    assert tuple(p.shape) == (9, 21, 64)
+    want = torch.zeros((9, 21, 64), dtype=dtype, device=DEV)
+    want[:, :, :40] = w.permute(2, 3, 0, 1).reshape(9, 21, 40).to(dtype)
+    assert torch.equal(p, want)
+    pt = ops.pack_weight(w, dtype, transpose=True)
+    assert tuple(pt.shape) == (9, 40, 32)
+    want = torch.zeros((9, 40, 32), dtype=dtype, device=DEV)
+    want[:, :, :21] = w.flip(2, 3).permute(2, 3, 1, 0).reshape(9, 40, 21).to(dtype)
+    assert torch.equal(pt, want)
+
+
+# -------------------------------------------------------------------- conv ----
+CONV_CASES = [
+    # N, H, W, Cin, Cout, R, dil
+    (2, 9, 7, 64, 48, 1, 1),
+    (1, 17, 23, 96, 256, 3, 1),
+    (2, 17, 23, 128, 130, 3, 2),
+    (2, 33, 33, 64, 64, 3, 6),
+    (1, 33, 33, 64, 32, 3, 12),
+    (1, 20, 33, 32, 21, 3, 18),
+    (2, 13, 11, 64, 16, 3, 36),
+]
+
+
+def _conv_inputs(case, integer=False):
+    N, H, W, Cin, Cout, R, dil = case
+    tag = "conv%s" % (case,)
+    if integer:
+        x = gen.integers(3, tag + "x", (N, Cin, H, W), -3, 4).astype(np.float32)
+        w = gen.integers(3, tag + "w", (Cout, Cin, R, R), -2, 3).astype(np.float32)
+    else:
+        x = gen.normal(3, tag + "x", (N, Cin, H, W))
+        w = gen.normal(3, tag + "w", (Cout, Cin, R, R), std=(2.0 / (Cin * R * R)) ** 0.5)
+    return T(x), T(w)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_fwd_exact_integers(ops, case, dtype):
+    """Small-integer operands make every product and sum exact in bf16 and fp32: any fragment-layout
+    or tap-indexing mistake shows up as a hard mismatch."""
+    N, H, W, Cin, Cout, R, dil = case
+    x, w = _conv_inputs(case, integer=True)
+    xv, _ = to_pm(x, dtype, ld=Cin + 32)
+    wp = ops.pack_weight(w, dtype)
+    out = torch.zeros((N * H * W, ops.round_up(Cout, 4) + 4), dtype=torch.float32, device=DEV)
+    ov = out[:, :ops.round_up(Cout, 4)]
+    stats = ops.conv_fwd([(xv, wp, R, dil)], N, H, W, Cout, ov, want_stats=True)
+    ref = F.conv2d(x, w, padding=dil * (R // 2), dilation=dil)
+    got = from_pm(ov[:, :Cout], N, H, W)
+    assert torch.equal(got, ref)
+    assert float(out[:, ops.round_up(Cout, 4):].abs().sum()) == 0
+    s = stats.sum(0)
+    assert torch.equal(s[0], ref.sum((0, 2, 3))) and torch.equal(s[1], (ref * ref).sum((0, 2, 3)))
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+def test_conv_fwd_random(ops, case, dtype, tol):
+    N, H, W, Cin, Cout, R, dil = case
+    x, w = _conv_inputs(case)
+    bias = T(gen.normal(3, "convb%s" % (case,), (Cout,)))
+    img_bias = T(gen.normal(3, "convib%s" % (case,), (N, Cout)))
+    xv, _ = to_pm(x, dtype)
+    wp = ops.pack_weight(w, dtype)
+    out = torch.zeros((N * H * W, ops.round_up(Cout, 4)), dtype=dtype, device=DEV)
+    ops.conv_fwd([(xv, wp, R, dil)], N, H, W, Cout, out, bias=bias, img_bias=img_bias)
+    ref = F.conv2d(x, w, bias, padding=dil * (R // 2), dilation=dil) + img_bias[:, :, None, None]
+    assert relerr(from_pm(out[:, :Cout], N, H, W), ref) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+def test_conv_multi_segment_is_sum(ops, dtype, tol):
+    """The ASPP data gradient: four branches (1x1, 3x3 at three rates) summed into one output."""
+    N, H, W, C, Cout = 2, 21, 19, 64, 96
+    segs, ref = [], 0
+    for i, (R, dil) in enumerate([(1, 1), (3, 6), (3, 12), (3, 18)]):
+        x = T(gen.normal(4, "ms_x%d" % i, (N, C, H, W)))
+        w = T(gen.normal(4, "ms_w%d" % i, (Cout, C, R, R), std=0.05))
+        segs.append((to_pm(x, dtype)[0], ops.pack_weight(w, dtype), R, dil))
+        ref = ref + F.conv2d(x, w, padding=dil * (R // 2), dilation=dil)
+    out = torch.empty((N * H * W, Cout), dtype=torch.float32, device=DEV)
+    ops.conv_fwd(segs, N, H, W, Cout, out)
+    assert relerr(from_pm(out, N, H, W), ref) < tol
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+def test_conv_dgrad(ops, case, dtype, tol):
+    N, H, W, Cin, Cout, R, dil = case
+    x, w = _conv_inputs(case)
+    x.requires_grad_(True)
+    y = F.conv2d(x, w, padding=dil * (R // 2), dilation=dil)
+    gy = T(gen.normal(5, "dg%s" % (case,), tuple(y.shape)))
+    (gx,) = torch.autograd.grad(y, x, gy)
+    cpad = ops.round_up(Cout, 32)
+    gv, _ = to_pm(gy, dtype, ld=cpad)
+    gfull = gv if cpad == Cout else _[:, :cpad]
+    wt = ops.pack_weight(w, dtype, transpose=True)
+    out = torch.empty((N * H * W, Cin), dtype=torch.float32, device=DEV)
+    ops.conv_fwd([(gfull, wt, R, dil)], N, H, W, Cin, out)
+    assert relerr(from_pm(out, N, H, W), gx) < tol
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("splits", [1, 3])
+def test_conv_wgrad_exact_integers(ops, case, dtype, splits):
+    N, H, W, Cin, Cout, R, dil = case
+    x, w = _conv_inputs(case, integer=True)
+    w.requires_grad_(True)
+    y = F.conv2d(x, w, padding=dil * (R // 2), dilation=dil)
+    gy = T(gen.integers(5, "wg%s" % (case,), tuple(y.shape), -2, 3).astype(np.float32))
+    (gw,) = torch.autograd.grad(y, w, gy)
+    cpad = ops.round_up(Cout, 16)
+    _, xfull = to_pm(x, dtype)
+    _, gfull = to_pm(gy, dtype, ld=cpad)
+    got = ops.conv_wgrad(xfull, gfull, N, H, W, R, dil, Cout, Cin, splits=splits)
+    assert torch.equal(got, gw)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+def test_conv_wgrad_random_padded_input(ops, dtype, tol):
+    """Decoder shape in miniature: 304 real input channels inside a 320-wide buffer."""
+    N, H, W, Cin, Cout, R, dil = 2, 19, 17, 304, 64, 3, 1
+    x = T(gen.normal(6, "wgp_x", (N, Cin, H, W)))
+    w = T(gen.normal(6, "wgp_w", (Cout, Cin, R, R), std=0.02)).requires_grad_(True)
+    y = F.conv2d(x, w, padding=1)
+    gy = T(gen.normal(6, "wgp_g", tuple(y.shape)))
+    (gw,) = torch.autograd.grad(y, w, gy)
+    _, xfull = to_pm(x, dtype, ld=320)
+    _, gfull = to_pm(gy, dtype)
+    got = ops.conv_wgrad(xfull, gfull, N, H, W, R, dil, Cout, Cin)
+    assert relerr(got, gw) < tol
+    # forward over the padded buffer as well
+    out = torch.empty((N * H * W, Cout), dtype=torch.float32, device=DEV)
+    ops.conv_fwd([(xfull, ops.pack_weight(w.detach(), dtype), R, dil)], N, H, W, Cout, out)
+    assert relerr(from_pm(out, N, H, W), y.detach()) < tol
+
+
+# ---------------------------------------------------------------------- BN ----
+def _bn_reference(x, g, b, relu, mask, mask_scale, gy, eps=1e-5):
+    x = x.clone().requires_grad_(True)
+    g = g.clone().requires_grad_(True)
+    b = b.clone().requires_grad_(True)
+    rm = torch.zeros_like(g)
+    rv = torch.ones_like(g)
+    y = F.batch_norm(x, rm, rv, g, b, True, 0.1, eps)
+    if relu:
+        y = F.relu(y)
+    if mask is not None:
+        y = y * mask.float() * mask_scale
+    y.backward(gy)
+    return y.detach(), x.grad, g.grad, b.grad, rm, rv
+
+
+@pytest.mark.parametrize("layout", ["pm", "nchw"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("C,shape", [(48, (2, 9, 11)), (256, (3, 7, 5)), (5, (4, 6, 3))])
+def test_bn_train(ops, layout, dtype, tol, C, shape):
+    from segk._lib import NCHW, PM
+    if layout == "pm" and C % 4 and dtype == torch.bfloat16:
+        pytest.skip("odd channel counts only occur in the fp32 NCHW feeder")
+    N, H, W = shape
+    tag = "bn%d%s" % (C, layout)
+    x = T(gen.normal(7, tag + "x", (N, C, H, W), std=2.0, mean=0.7)).to(dtype).float()
+    g = T(gen.uniform(7, tag + "g", (C,), 0.5, 1.5))
+    b = T(gen.normal(7, tag + "b", (C,)))
+    gy = T(gen.normal(7, tag + "gy", (N, C, H, W))).to(dtype).float()
+    keep = T((gen.uniform(7, tag + "m", (N, C, H, W)) > 0.3).astype(np.uint8))
+    y_ref, dx_ref, dg_ref, db_ref, rm_ref, rv_ref = _bn_reference(x, g, b, True, keep, 1 / 0.7, gy)
+    rm = torch.zeros(C, device=DEV)
+    rv = torch.ones(C, device=DEV)
+    if layout == "pm":
+        L = PM
+        xv, _ = to_pm(x, dtype, ld=C + 8)
+        gv, _ = to_pm(gy, dtype, ld=C + 4)
+        mv = keep.permute(0, 2, 3, 1).reshape(-1, C).contiguous()
+        yv = torch.zeros((N * H * W, C + 12), dtype=dtype, device=DEV)[:, 4:4 + C]
+        dxv = torch.zeros((N * H * W, C), dtype=dtype, device=DEV)
+    else:
+        L = NCHW
+        xv, gv, mv = x.to(dtype).contiguous(), gy.to(dtype).contiguous(), keep.contiguous()
+        yv, dxv = torch.empty_like(xv), torch.empty_like(xv)
+    sums = ops.bn_local_sums(xv, L)
+    assert abs(float(sums[-1]) - N * H * W) < 0.5
+    coef = ops.bn_coeffs(sums, g, b, 1e-5, 0.1, rm, rv)
+    ops.bn_apply(xv, yv, coef, L, True, mv, 1 / 0.7)
+    gs = ops.bn_bwd_local_sums(gv, xv, coef, L, True, mv, 1 / 0.7)
+    ops.bn_bwd_apply(gv, xv, dxv, coef, gs, L, True, mv, 1 / 0.7)
+    y = from_pm(yv, N, H, W) if layout == "pm" else yv.float()
+    dx = from_pm(dxv, N, H, W) if layout == "pm" else dxv.float()
+    assert relerr(y, y_ref) < tol
+    assert relerr(dx, dx_ref) < tol * 5
+    assert relerr(gs[:C], db_ref) < tol * 5 and relerr(gs[C:2 * C], dg_ref) < tol * 5
+    assert relerr(rm, rm_ref) < 1e-5 and relerr(rv, rv_ref) < 1e-4
+
+
+def test_bn_clamp_and_eval(ops):
+    """legacy clamp(var, eps)^-1/2 against the fixture of the reference's _compute_mean_std, and eval mode."""
+    from helpers import load_golden
+    from segk._lib import NCHW
+    want = load_golden("syncbn")
+    C = 12
+    sums = torch.cat([T(want["sum"]), T(want["ssum"]), torch.tensor([6 * 5 * 7.0], device=DEV)])
+    rm = T(gen.normal(20240607, "syncbn/rm", (C,), std=0.1))
+    rv = T(gen.uniform(20240607, "syncbn/rv", (C,), 0.5, 1.5))
+    coef = ops.bn_coeffs(sums, None, None, 1e-5, 0.1, rm, rv, legacy_clamp=True)
+    assert relerr(coef[0], T(want["mean"])) < 1e-6
+    assert relerr(coef[1], T(want["inv_std"])) < 1e-5
+    assert relerr(rm, T(want["running_mean"])) < 1e-6 and relerr(rv, T(want["running_var"])) < 1e-5
+    x = T(gen.normal(8, "bneval", (2, C, 4, 5)))
+    g, b = T(gen.uniform(8, "g", (C,), 0.5, 1.5)), T(gen.normal(8, "b", (C,)))
+    ce = ops.bn_coeffs_eval(rm, rv, g, b, 1e-5)
+    y = ops.bn_apply(x, torch.empty_like(x), ce, NCHW, False)
+    assert relerr(y, F.batch_norm(x, rm, rv, g, b, False, 0.1, 1e-5)) < 1e-5
+
+
+# ---------------------------------------------------------------- resample ----
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+def test_pool_sum(ops, dtype, tol):
+    x = T(gen.normal(9, "pool", (3, 320, 9, 11))).to(dtype).float()
+    xv, _ = to_pm(x, dtype, ld=352)
+    got = ops.pool_sum(xv, 3, 99, 1.0 / 99)
+    assert relerr(got, x.mean((2, 3))) < tol
+
+
+UP_CASES = [((2, 8, 1, 1), (5, 7)), ((1, 16, 9, 11), (33, 41)), ((2, 256, 33, 33), (129, 129)),
+            ((1, 8, 97, 97), (193, 193)), ((2, 12, 7, 5), (20, 13)), ((1, 4, 6, 6), (6, 6)), ((1, 4, 8, 8), (1, 1))]
+
+
+@pytest.mark.parametrize("shape,size", UP_CASES)
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+def test_upsample_pm(ops, shape, size, dtype, tol):
+    from segk._lib import PM
+    N, C, Hi, Wi = shape
+    Ho, Wo = size
+    x = T(gen.normal(10, "up%s" % (shape,), shape)).to(dtype).float().requires_grad_(True)
+    y_ref = F.interpolate(x, size=size, mode="bilinear", align_corners=True)
+    gy = T(gen.normal(10, "upg%s" % (shape,), tuple(y_ref.shape))).to(dtype).float()
+    (gx_ref,) = torch.autograd.grad(y_ref, x, gy)
+    xv, _ = to_pm(x.detach(), dtype, ld=C + 4)
+    yv = torch.zeros((N * Ho * Wo, C + 8), dtype=dtype, device=DEV)[:, 4:4 + C]
+    ops.upsample_fwd(xv, N, C, Hi, Wi, yv, Ho, Wo, PM)
+    assert relerr(from_pm(yv, N, Ho, Wo), y_ref.detach()) < tol
+    gv, _ = to_pm(gy, dtype, ld=C + 4)
+    din = torch.full((N * Hi * Wi, C + 8), 7.0, dtype=dtype, device=DEV)
+    ops.upsample_bwd(gv, PM, N, C, Ho, Wo, din[:, :C + 4], C + 4, Hi, Wi)
+    assert relerr(from_pm(din[:, :C], N, Hi, Wi), gx_ref) < tol * 2
+    assert float(din[:, C:C + 4].abs().sum()) == 0 and float((din[:, C + 4:] - 7).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("K", [21, 19, 81, 8])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+def test_upsample_to_nchw_logits(ops, K, dtype, tol):
+    from segk._lib import NCHW
+    N, Hi, Wi, Ho, Wo = 2, 17, 13, 65, 49
+    x = T(gen.normal(11, "upl%d" % K, (N, K, Hi, Wi))).to(dtype).float().requires_grad_(True)
+    y_ref = F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=True)
+    gy = T(gen.normal(11, "uplg%d" % K, tuple(y_ref.shape)))
+    (gx_ref,) = torch.autograd.grad(y_ref, x, gy)
+    ld = ops.round_up(K, 32)
+    xv, _ = to_pm(x.detach(), dtype, ld=ld)
+    y = torch.empty((N, K, Ho, Wo), dtype=torch.float32, device=DEV)
+    ops.upsample_fwd(xv, N, K, Hi, Wi, y, Ho, Wo, NCHW)
+    assert relerr(y, y_ref.detach()) < tol
+    din = torch.full((N * Hi * Wi, ld), 3.0, dtype=dtype, device=DEV)
+    ops.upsample_bwd(gy, NCHW, N, K, Ho, Wo, din, ld, Hi, Wi)
+    assert relerr(from_pm(din[:, :K], N, Hi, Wi), gx_ref) < tol * 2
+    assert float(din[:, K:].abs().sum()) == 0
+
+
+# -------------------------------------------------------------------- loss ----
+@pytest.mark.parametrize("name,K", [("plain", 21), ("one_image_ignored", 21), ("weighted", 21), ("k81", 81), ("k8", 8)])
+def test_ce_kernels(ops, name, K):
+    from oracle import cases
+    logit_np, target_np, weight_np = cases.ce_inputs(name, K=K)
+    logit, target = T(logit_np), T(target_np)
+    weight = None if weight_np is None else T(weight_np)
+    sums, lse = ops.ce_fwd(logit, target, weight, 255)
+    lref = logit.clone().requires_grad_(True)
+    ref = F.cross_entropy(lref, target.long(), weight=weight, ignore_index=255, reduction="sum")
+    assert relerr(sums[0:1], ref.detach().reshape(1)) < 1e-5
+    assert relerr(lse, torch.logsumexp(logit, dim=1)) < 1e-6
+    ref.backward()
+    coef = torch.ones(1, device=DEV)
+    dl = ops.ce_bwd(logit, target, weight, lse, 255, coef)
+    assert relerr(dl, lref.grad) < 1e-5
+
+
+@pytest.mark.parametrize("K", [8, 19, 21, 81, 200])
+def test_argmax_and_confmat_bit_exact(ops, K):
+    from oracle import cases
+    gt_np, logits_np = cases.eval_inputs(min(K, 81))
+    if K > 81:
+        logits_np = gen.normal(12, "bigk", (3, K, 37, 41))
+        gt_np = gen.labels(12, "bigk/gt", (3, 37, 41), K, border=1)
+    logits_np[0, 0, 0, :5] = np.nan
+    logits_np[0, 2, 0, 2:7] = np.nan
+    pred_np = np.argmax(logits_np, axis=1)
+    pred = ops.argmax(T(logits_np))
+    assert np.array_equal(pred.cpu().numpy(), pred_np)
+    cm = torch.zeros(K * K + 1, dtype=torch.int64, device=DEV)
+    ops.confmat_accumulate(T(gt_np), pred, K, cm)
+    ops.confmat_accumulate(T(gt_np), pred, K, cm)
+    want = 2 * ops_ref.confusion_matrix(gt_np, pred_np, K)
+    assert np.array_equal(cm[:-1].cpu().numpy().reshape(K, K), want)
+    assert int(cm[-1]) == 0
+    # int64 labels and an out-of-range prediction
+    cm.zero_()
+    bad = pred.clone()
+    bad.view(-1)[7] = K + 3
+    gt_i = T(np.where((gt_np >= 0) & (gt_np < K), gt_np, -1).astype(np.int64))
+    ops.confmat_accumulate(gt_i, bad, K, cm)
+    valid7 = 0 <= gt_np.reshape(-1)[7] < K
+    assert int(cm[-1]) == (1 if valid7 else 0)
