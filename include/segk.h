@@ -84,7 +84,7 @@ typedef struct {
   int out_dtype;
   const float* bias;      /* [Cout] or NULL (modeling/decoder.py:152-153, classifier) */
   const float* img_bias;  /* [N][Cout] or NULL: added to every pixel of image n */
-  float* stat_partials;   /* NULL, or [segk_conv_stat_rows(&a)][2][Cout] fp32: per-row-tile sum and
+  double* stat_partials;  /* NULL, or [segk_conv_stat_rows(&a)][2][Cout] fp64: per-row-tile sum and
                              sum of squares of the UNBIASED output, for batch-norm statistics */
 } segk_conv_args;
 
@@ -119,19 +119,21 @@ int segk_wgrad_finish(const float* slabs, int splits, int R, int Cin, int Cout, 
 /* Layouts for the BN entry points. */
 typedef enum { SEGK_PM = 0 /* [M][ld], channels contiguous */, SEGK_NCHW = 1 /* [N][C][HW] */ } segk_layout;
 
-/* Per-channel sum and sum of squares (modeling/sync_batchnorm/batchnorm.py:60-62).
- * partials: [segk_bn_stat_rows(...)][2][C] fp32. */
-int segk_bn_stats(const void* x, int dtype, int layout, int N, int C, int HW, int ld, float* partials,
+/* Per-channel sum and sum of squares (modeling/sync_batchnorm/batchnorm.py:60-62), accumulated in fp64
+ * (the square of an fp32 value is exact in fp64, so var = E[x^2] - E[x]^2 does not cancel catastrophically
+ * even for the image-pooling branch, whose few samples per channel are nearly equal).
+ * partials: [segk_bn_stat_rows(...)][2][C] fp64. */
+int segk_bn_stats(const void* x, int dtype, int layout, int N, int C, int HW, int ld, double* partials,
                   segk_stream_t stream);
 int segk_bn_stat_rows(int layout, int N, int C, int HW);
-/* Sum `rows` partial rows in index order: sums[0..C) = sum x, sums[C..2C) = sum x^2, sums[2C] = count.
- * The [2C+1] vector is what ranks all-reduce (replaces ReduceAddCoalesced, batchnorm.py:101-102). */
-int segk_bn_reduce(const float* partials, int rows, int C, float count, float* sums, segk_stream_t stream);
+/* Sum `rows` partial rows in index order: sums[0..C) = first sum, sums[C..2C) = second sum, sums[2C] = count.
+ * The [2C+1] fp64 vector is what ranks all-reduce (replaces ReduceAddCoalesced, batchnorm.py:101-102). */
+int segk_bn_reduce(const double* partials, int rows, int C, double count, double* sums, segk_stream_t stream);
 /* Global sums -> mean, inv_std, running statistics and the affine coefficients
  * scale = gamma*inv_std, shift = beta - mean*scale (batchnorm.py:113-125 and :73).
  * legacy_clamp != 0: inv_std = clamp(var, eps)^-1/2 (batchnorm.py:125); 0: (var + eps)^-1/2 (F.batch_norm,
  * batchnorm.py:50-53).  running_* may be NULL.  gamma/beta NULL = 1/0. */
-int segk_bn_coeffs(const float* sums, const float* gamma, const float* beta, float eps, float momentum,
+int segk_bn_coeffs(const double* sums, const float* gamma, const float* beta, float eps, float momentum,
                    int legacy_clamp, float* running_mean, float* running_var, float* mean, float* inv_std,
                    float* scale, float* shift, int C, segk_stream_t stream);
 /* Evaluation mode (batchnorm.py:50-53 with training False): coefficients from running statistics. */
@@ -148,7 +150,7 @@ int segk_bn_apply(const void* x, int x_dtype, int x_ld, void* y, int y_dtype, in
  * partials: [segk_bn_stat_rows(...)][2][C]. */
 int segk_bn_bwd_stats(const void* dz, int dz_dtype, int dz_ld, const void* x, int x_dtype, int x_ld, int layout,
                       int N, int C, int HW, const float* mean, const float* inv_std, const float* scale,
-                      const float* shift, int relu, const uint8_t* mask, float mask_scale, float* partials,
+                      const float* shift, int relu, const uint8_t* mask, float mask_scale, double* partials,
                       segk_stream_t stream);
 /* Backward, pass 2: dx = scale * (g - sum_g/count - xhat * sum_gxhat/count) with the GLOBAL sums
  * gsums = [sum g (C), sum g*xhat (C), count] (autograd of batchnorm.py:66-73 through the reduction);
@@ -156,7 +158,7 @@ int segk_bn_bwd_stats(const void* dz, int dz_dtype, int dz_ld, const void* x, in
 int segk_bn_bwd_apply(const void* dz, int dz_dtype, int dz_ld, const void* x, int x_dtype, int x_ld, void* dx,
                       int dx_dtype, int dx_ld, int layout, int N, int C, int HW, const float* mean,
                       const float* inv_std, const float* scale, const float* shift, int relu,
-                      const uint8_t* mask, float mask_scale, const float* gsums, int eval,
+                      const uint8_t* mask, float mask_scale, const double* gsums, int eval,
                       segk_stream_t stream);
 
 /* ---- pooling / resampling ------------------------------------------------------------------- */

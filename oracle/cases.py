@@ -58,6 +58,19 @@ def _zero_dropout(module):
             m.p = 0.0
 
 
+def _gain(n, c=1, tag="gain"):
+    """Per-image, per-channel scale in [0.5, 1.5) so that images differ the way real ones do.  Without it
+    the image-pooling branch of ASPP sees near-identical pooled vectors, its batch norm divides by
+    sqrt(var + eps) with var ~ eps, and the rounding noise of any implementation is amplified a thousandfold;
+    with a per-image scale only, pooled vectors are collinear and that branch's weight gradient cancels to
+    noise.  Both are ill-conditioned tests, not kernel properties.  (For the same reason the cases use >= 3
+    images wherever that branch is differentiated: batch norm over two samples maps them to +-1 whatever
+    their values, so its input gradient is pure cancellation.)"""
+    if c == 1:
+        return np.linspace(0.5, 1.5, n, dtype=np.float32).reshape(n, 1, 1, 1)
+    return gen.uniform(SEED, tag, (n, c, 1, 1), 0.5, 1.5)
+
+
 def _sample(a, count=4096):
     flat = np.asarray(a).reshape(-1)
     step = max(1, flat.size // count)
@@ -92,7 +105,7 @@ def case_branch(impl, k, dil, cin=24, cout=16, shape=(2, 17, 23)):
 
 
 # ---------------------------------------------------------------- (2) ASPP ----
-def case_aspp(impl, backbone="mobilenet", output_stride=16, shape=(2, 9, 11), inplanes=320):
+def case_aspp(impl, backbone="mobilenet", output_stride=16, shape=(4, 9, 11), inplanes=320):
     n, h, w = shape
     tag = "aspp_%s_os%d" % (backbone, output_stride)
     out = {}
@@ -100,7 +113,7 @@ def case_aspp(impl, backbone="mobilenet", output_stride=16, shape=(2, 9, 11), in
         m = _load(impl.ASPP(backbone, output_stride, impl.BatchNorm), SEED, tag, impl.device)
         _zero_dropout(m)
         m.train(mode == "train")
-        x = _t(gen.relu_normal(SEED, tag + "/x", (n, inplanes, h, w)), impl.device, grad=True)
+        x = _t(gen.relu_normal(SEED, tag + "/x", (n, inplanes, h, w)) * _gain(n, inplanes), impl.device, grad=True)
         y = m(x)
         gy = _t(gen.normal(SEED, tag + "/gy", tuple(y.shape)), impl.device)
         y.backward(gy)
@@ -120,8 +133,10 @@ def case_decoder(impl, num_classes=21, shape_x=(2, 5, 7), shape_low=(2, 17, 25))
         m = _load(impl.Decoder(num_classes, "resnet", impl.BatchNorm), SEED, tag, impl.device)
         _zero_dropout(m)
         m.train(mode == "train")
-        x = _t(gen.relu_normal(SEED, tag + "/x", (shape_x[0], 256) + shape_x[1:]), impl.device, grad=True)
-        low = _t(gen.relu_normal(SEED, tag + "/low", (shape_low[0], 256) + shape_low[1:]), impl.device, grad=True)
+        x = _t(gen.relu_normal(SEED, tag + "/x", (shape_x[0], 256) + shape_x[1:]) * _gain(shape_x[0], 256), impl.device,
+               grad=True)
+        low = _t(gen.relu_normal(SEED, tag + "/low", (shape_low[0], 256) + shape_low[1:]) * _gain(shape_low[0], 256, "gainlow"),
+                 impl.device, grad=True)
         y = m(x, low)
         gy = _t(gen.normal(SEED, tag + "/gy", tuple(y.shape)), impl.device)
         y.backward(gy)
@@ -216,7 +231,7 @@ def case_eval(impl, K):
 
 
 # --------------------------------------------------------- (8) end to end ----
-def case_e2e(impl, steps=2, n=2, size=65, K=21, base_lr=0.007, total_iters=100):
+def case_e2e(impl, steps=2, n=4, size=65, K=21, base_lr=0.007, total_iters=100):
     """Two SGD steps of the whole model the way the trainers drive it
     (/root/reference/tain_origin.py:124-147; groups and hyper-parameters
     /root/reference/train.py:56-61): poly LR, zero_grad, forward, CE, backward, step."""
@@ -230,7 +245,7 @@ def case_e2e(impl, steps=2, n=2, size=65, K=21, base_lr=0.007, total_iters=100):
     out = {}
     losses = []
     for it in range(steps):
-        image = _t(gen.normal(SEED, tag + "/img%d" % it, (n, 3, size, size)), impl.device)
+        image = _t(gen.normal(SEED, tag + "/img%d" % it, (n, 3, size, size)) * _gain(n), impl.device)
         target = _t(gen.labels(SEED, tag + "/lab%d" % it, (n, size, size), K, border=2), impl.device)
         lr = base_lr * pow((1 - 1.0 * it / total_iters), 0.9)
         opt.param_groups[0]["lr"] = lr
@@ -255,7 +270,7 @@ def case_e2e(impl, steps=2, n=2, size=65, K=21, base_lr=0.007, total_iters=100):
 
 
 # ------------------------------------------------- (9) full-size summaries ----
-def case_fullsize(impl, config="A", n=2, backward=True):
+def case_fullsize(impl, config="A", n=3, backward=True):
     """Head only, at BASELINE shapes.  A: OS16 513^2 K=21 (x 33^2, low 129^2);
     D: OS8 769^2 K=19 (x 97^2, low 193^2)."""
     if config == "A":
@@ -268,8 +283,8 @@ def case_fullsize(impl, config="A", n=2, backward=True):
     for m in (aspp, dec):
         _zero_dropout(m)
         m.train()
-    x = _t(gen.relu_normal(SEED, tag + "/x", (n, 2048, h, h)), impl.device, grad=backward)
-    low = _t(gen.relu_normal(SEED, tag + "/low", (n, 256, l, l)), impl.device, grad=backward)
+    x = _t(gen.relu_normal(SEED, tag + "/x", (n, 2048, h, h)) * _gain(n, 2048), impl.device, grad=backward)
+    low = _t(gen.relu_normal(SEED, tag + "/low", (n, 256, l, l)) * _gain(n, 256, "gainlow"), impl.device, grad=backward)
     target = _t(gen.labels(SEED, tag + "/lab", (n, H, H), K, border=10), impl.device)
     a = aspp(x)
     d = dec(a, low)

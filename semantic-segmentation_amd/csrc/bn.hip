@@ -64,9 +64,9 @@ struct PmGeom {
 };
 
 // Combine the per-thread accumulators a[VEC], b[VEC] of all pixel rows of the block and write one partial row.
-template <int VEC>
-__device__ __forceinline__ void block_reduce_pm(float (&a)[VEC], float (&b)[VEC], int C, PmGeom g, float* out_row) {
-  __shared__ float red[2 * BN_THREADS * 4];
+template <int VEC, typename ACC>
+__device__ __forceinline__ void block_reduce_pm(ACC (&a)[VEC], ACC (&b)[VEC], int C, PmGeom g, double* out_row) {
+  __shared__ ACC red[2 * BN_THREADS * 4];
   const int cgi = threadIdx.x % g.cg, pr = threadIdx.x / g.cg;
   const bool active = pr < g.rpb;
   // layout red[pr][2][C]
@@ -79,19 +79,20 @@ __device__ __forceinline__ void block_reduce_pm(float (&a)[VEC], float (&b)[VEC]
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * C; i += BN_THREADS) {
-    float s = 0.f;
-    for (int r = 0; r < g.rpb; ++r) s += red[r * 2 * C + i];
+    double s = 0.0;
+    for (int r = 0; r < g.rpb; ++r) s += (double)red[r * 2 * C + i];
     out_row[i] = s;
   }
 }
 
 template <typename TX, int VEC>
 __global__ __launch_bounds__(BN_THREADS) void bn_stats_pm_kernel(const TX* __restrict__ x, int ld, long long M, int C,
-                                                                  PmGeom g, float* __restrict__ partials) {
+                                                                  PmGeom g, double* __restrict__ partials) {
   const int cgi = threadIdx.x % g.cg, pr = threadIdx.x / g.cg;
-  float a[VEC], b[VEC];
+  // fp64 accumulation: squares of fp32 values are exact in fp64, so E[x^2] - E[x]^2 loses nothing
+  double a[VEC], b[VEC];
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) a[j] = b[j] = 0.f;
+  for (int j = 0; j < VEC; ++j) a[j] = b[j] = 0.0;
   const long long per = (M + gridDim.x - 1) / gridDim.x;
   const long long m0 = (long long)blockIdx.x * per;
   const long long m1 = m0 + per < M ? m0 + per : M;
@@ -101,12 +102,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_pm_kernel(const TX* __res
       load_vec<TX, VEC>(x + m * ld + cgi * VEC, v);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        a[j] += v[j];
-        b[j] = fmaf(v[j], v[j], b[j]);
+        const double d = (double)v[j];
+        a[j] += d;
+        b[j] = fma(d, d, b[j]);
       }
     }
   }
-  block_reduce_pm<VEC>(a, b, C, g, partials + (size_t)blockIdx.x * 2 * C);
+  block_reduce_pm<VEC, double>(a, b, C, g, partials + (size_t)blockIdx.x * 2 * C);
 }
 
 // g = dz * mask * mask_scale * [x*scale+shift > 0]
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_pm_kernel(
     const TG* __restrict__ dz, int dz_ld, const TX* __restrict__ x, int x_ld, long long M, int C, PmGeom g,
     const float* __restrict__ mean, const float* __restrict__ inv_std, const float* __restrict__ scale,
     const float* __restrict__ shift, int relu, const uint8_t* __restrict__ mask, float mask_scale,
-    float* __restrict__ partials) {
+    double* __restrict__ partials) {
   const int cgi = threadIdx.x % g.cg, pr = threadIdx.x / g.cg;
   float a[VEC], b[VEC], mu[VEC], is[VEC], sc[VEC], sh[VEC];
 #pragma unroll
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_pm_kernel(
       }
     }
   }
-  block_reduce_pm<VEC>(a, b, C, g, partials + (size_t)blockIdx.x * 2 * C);
+  block_reduce_pm<VEC, float>(a, b, C, g, partials + (size_t)blockIdx.x * 2 * C);
 }
 
 template <typename TX, typename TY, int VEC>
@@ -192,9 +194,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_pm_kernel(
     const TG* __restrict__ dz, int dz_ld, const TX* __restrict__ x, int x_ld, TG* __restrict__ dx, int dx_ld,
     long long M, int C, int cg, const float* __restrict__ mean, const float* __restrict__ inv_std,
     const float* __restrict__ scale, const float* __restrict__ shift, int relu, const uint8_t* __restrict__ mask,
-    float mask_scale, const float* __restrict__ gsums, int eval) {
+    float mask_scale, const double* __restrict__ gsums, int eval) {
   const long long total = M * cg;
-  const float inv_count = eval ? 0.f : 1.f / gsums[2 * C];
+  const float inv_count = eval ? 0.f : (float)(1.0 / gsums[2 * C]);
   for (long long i = (long long)blockIdx.x * BN_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * BN_THREADS) {
     const long long m = i / cg;
     const int c0 = (int)(i - m * cg) * VEC;
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_pm_kernel(
         o[j] = sc[j] * gz[j];
       } else {
         const float xh = (xv[j] - mean[c]) * inv_std[c];
-        o[j] = sc[j] * (gz[j] - gsums[c] * inv_count - xh * (gsums[C + c] * inv_count));
+        o[j] = sc[j] * (gz[j] - (float)gsums[c] * inv_count - xh * ((float)gsums[C + c] * inv_count));
       }
     }
     store_vec<TG, VEC>(dx + m * dx_ld + c0, o);
@@ -221,8 +223,15 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_pm_kernel(
 // ---------------------------------------------------------------------------------------------
 // NCHW kernels: block (c, s) reduces pixel slice s of channel c over all images.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void block_reduce2(float& a, float& b) {
-  __shared__ float ra[BN_THREADS / 64], rb[BN_THREADS / 64];
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename ACC>
+__device__ __forceinline__ void block_reduce2(ACC& a, ACC& b) {
+  __shared__ ACC ra[BN_THREADS / 64], rb[BN_THREADS / 64];
   a = wave_sum(a);
   b = wave_sum(b);
   const int w = threadIdx.x >> 6;
@@ -234,17 +243,17 @@ __device__ __forceinline__ void block_reduce2(float& a, float& b) {
 
 template <typename TX>
 __global__ __launch_bounds__(BN_THREADS) void bn_stats_nchw_kernel(const TX* __restrict__ x, int N, int C, int HW,
-                                                                    float* __restrict__ partials) {
+                                                                    double* __restrict__ partials) {
   const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
   const int per = (HW + S - 1) / S;
   const int p0 = s * per, p1 = min(HW, p0 + per);
-  float a = 0.f, b = 0.f;
+  double a = 0.0, b = 0.0;
   for (int n = 0; n < N; ++n) {
     const TX* row = x + ((size_t)n * C + c) * HW;
     for (int p = p0 + threadIdx.x; p < p1; p += BN_THREADS) {
-      float v = Elem<TX>::load(row + p);
+      const double v = (double)Elem<TX>::load(row + p);
       a += v;
-      b = fmaf(v, v, b);
+      b = fma(v, v, b);
     }
   }
   block_reduce2(a, b);
@@ -258,7 +267,7 @@ template <typename TG, typename TX>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_nchw_kernel(
     const TG* __restrict__ dz, const TX* __restrict__ x, int N, int C, int HW, const float* __restrict__ mean,
     const float* __restrict__ inv_std, const float* __restrict__ scale, const float* __restrict__ shift, int relu,
-    const uint8_t* __restrict__ mask, float mask_scale, float* __restrict__ partials) {
+    const uint8_t* __restrict__ mask, float mask_scale, double* __restrict__ partials) {
   const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
   const int per = (HW + S - 1) / S;
   const int p0 = s * per, p1 = min(HW, p0 + per);
@@ -305,14 +314,14 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_nchw_kernel(
     const TG* __restrict__ dz, const TX* __restrict__ x, TG* __restrict__ dx, int C, int HW,
     const float* __restrict__ mean, const float* __restrict__ inv_std, const float* __restrict__ scale,
     const float* __restrict__ shift, int relu, const uint8_t* __restrict__ mask, float mask_scale,
-    const float* __restrict__ gsums, int eval) {
+    const double* __restrict__ gsums, int eval) {
   const int c = blockIdx.x % C;
   const size_t base = (size_t)blockIdx.x * HW;
   const int per = (HW + gridDim.y - 1) / gridDim.y;
   const int p0 = blockIdx.y * per, p1 = min(HW, p0 + per);
   const float mu = mean[c], is = inv_std[c], sc = scale[c], sh = shift[c];
-  const float inv_count = eval ? 0.f : 1.f / gsums[2 * C];
-  const float k1 = eval ? 0.f : gsums[c] * inv_count, k2 = eval ? 0.f : gsums[C + c] * inv_count;
+  const float inv_count = eval ? 0.f : (float)(1.0 / gsums[2 * C]);
+  const float k1 = eval ? 0.f : (float)gsums[c] * inv_count, k2 = eval ? 0.f : (float)gsums[C + c] * inv_count;
   for (int p = p0 + threadIdx.x; p < p1; p += BN_THREADS) {
     float g = Elem<TG>::load(dz + base + p);
     const float v = Elem<TX>::load(x + base + p);
@@ -324,11 +333,11 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_nchw_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ void bn_reduce_kernel(const float* __restrict__ partials, int rows, int C, float count,
-                                 float* __restrict__ sums) {
+__global__ void bn_reduce_kernel(const double* __restrict__ partials, int rows, int C, double count,
+                                 double* __restrict__ sums) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 2 * C) {
-    float s = 0.f;
+    double s = 0.0;
     for (int r = 0; r < rows; ++r) s += partials[(size_t)r * 2 * C + i];
     sums[i] = s;
   } else if (i == 2 * C) {
@@ -336,16 +345,16 @@ __global__ void bn_reduce_kernel(const float* __restrict__ partials, int rows, i
   }
 }
 
-__global__ void bn_coeffs_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
+__global__ void bn_coeffs_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
                                  const float* __restrict__ beta, float eps, float momentum, int legacy_clamp,
                                  float* __restrict__ running_mean, float* __restrict__ running_var,
                                  float* __restrict__ mean, float* __restrict__ inv_std, float* __restrict__ scale,
                                  float* __restrict__ shift, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  // the final cancellation (sum of squares minus mean*sum) is done in double
-  const double cnt = (double)sums[2 * C];
-  const double s = (double)sums[c], q = (double)sums[C + c];
+  // sums are fp64 end to end (exact squares, fp64 accumulation), so this cancellation is harmless
+  const double cnt = sums[2 * C];
+  const double s = sums[c], q = sums[C + c];
   const double mu = s / cnt;
   double sumvar = q - s * mu;
   if (sumvar < 0.0) sumvar = 0.0;
@@ -435,7 +444,7 @@ extern "C" int segk_bn_stat_rows(int layout, int N, int C, int HW) {
   return layout == SEGK_PM ? pm_rows((long long)N * HW) : nchw_rows(N, HW);
 }
 
-extern "C" int segk_bn_stats(const void* x, int dtype, int layout, int N, int C, int HW, int ld, float* partials,
+extern "C" int segk_bn_stats(const void* x, int dtype, int layout, int N, int C, int HW, int ld, double* partials,
                              segk_stream_t stream) {
   SEGK_REQUIRE(x && partials && valid_dtype(dtype), "bn_stats: null pointer or bad dtype");
   BN_COMMON_CHECK("bn_stats");
@@ -461,14 +470,15 @@ extern "C" int segk_bn_stats(const void* x, int dtype, int layout, int N, int C,
   return SEGK_OK;
 }
 
-extern "C" int segk_bn_reduce(const float* partials, int rows, int C, float count, float* sums, segk_stream_t stream) {
+extern "C" int segk_bn_reduce(const double* partials, int rows, int C, double count, double* sums,
+                              segk_stream_t stream) {
   SEGK_REQUIRE(partials && sums && rows > 0 && C > 0, "bn_reduce: bad arguments rows=%d C=%d", rows, C);
   bn_reduce_kernel<<<ceil_div(2 * C + 1, 256), 256, 0, (hipStream_t)stream>>>(partials, rows, C, count, sums);
   SEGK_CHECK_LAUNCH("bn_reduce");
   return SEGK_OK;
 }
 
-extern "C" int segk_bn_coeffs(const float* sums, const float* gamma, const float* beta, float eps, float momentum,
+extern "C" int segk_bn_coeffs(const double* sums, const float* gamma, const float* beta, float eps, float momentum,
                               int legacy_clamp, float* running_mean, float* running_var, float* mean, float* inv_std,
                               float* scale, float* shift, int C, segk_stream_t stream) {
   SEGK_REQUIRE(sums && mean && inv_std && scale && shift && C > 0, "bn_coeffs: null pointer or C=%d", C);
@@ -535,7 +545,7 @@ extern "C" int segk_bn_apply(const void* x, int x_dtype, int x_ld, void* y, int 
 extern "C" int segk_bn_bwd_stats(const void* dz, int dz_dtype, int dz_ld, const void* x, int x_dtype, int x_ld,
                                  int layout, int N, int C, int HW, const float* mean, const float* inv_std,
                                  const float* scale, const float* shift, int relu, const uint8_t* mask,
-                                 float mask_scale, float* partials, segk_stream_t stream) {
+                                 float mask_scale, double* partials, segk_stream_t stream) {
   SEGK_REQUIRE(dz && x && mean && inv_std && scale && shift && partials && valid_dtype(dz_dtype) && valid_dtype(x_dtype),
                "bn_bwd_stats: null pointer or bad dtype");
   BN_COMMON_CHECK("bn_bwd_stats");
@@ -579,7 +589,7 @@ extern "C" int segk_bn_bwd_stats(const void* dz, int dz_dtype, int dz_ld, const 
 extern "C" int segk_bn_bwd_apply(const void* dz, int dz_dtype, int dz_ld, const void* x, int x_dtype, int x_ld, void* dx,
                                  int dx_dtype, int dx_ld, int layout, int N, int C, int HW, const float* mean,
                                  const float* inv_std, const float* scale, const float* shift, int relu,
-                                 const uint8_t* mask, float mask_scale, const float* gsums, int eval,
+                                 const uint8_t* mask, float mask_scale, const double* gsums, int eval,
                                  segk_stream_t stream) {
   SEGK_REQUIRE(dz && x && dx && mean && inv_std && scale && shift && valid_dtype(dz_dtype) && valid_dtype(x_dtype),
                "bn_bwd_apply: null pointer or bad dtype");

@@ -43,7 +43,7 @@ struct ConvDev {
   int out_ld;
   const float* bias;
   const float* img_bias;
-  float* stat;
+  double* stat;
 };
 
 template <typename T>
@@ -257,19 +257,20 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_fwd_kernel(const ConvDev
   // ---- epilogue: acc[i][j][r] = out[pixel = wc*64 + j*16 + (lane&15)][co = wr*64 + i*16 + (lane>>4)*4 + r]
   const int fq = lane >> 4, fr = lane & 15;
   if (p.stat) {
-    float* red = reinterpret_cast<float*>(smem);  // [2 pixel halves][2][128]
+    // fp64 sums: the squares of the fp32 accumulators are exact in fp64
+    double* red = reinterpret_cast<double*>(smem);  // [2 pixel halves][2][128]
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float s[4], q[4];
+      double s[4], q[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        s[r] = 0.f;
-        q[r] = 0.f;
+        s[r] = 0.0;
+        q[r] = 0.0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float v = acc[i][j][r];
+          const double v = (double)acc[i][j][r];
           s[r] += v;
-          q[r] = fmaf(v, v, q[r]);
+          q[r] = fma(v, v, q[r]);
         }
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) {

@@ -47,7 +47,7 @@ SIGNATURES = {
     "segk_wgrad_finish": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
     "segk_bn_stats": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "segk_bn_stat_rows": [c_int, c_int, c_int, c_int],
-    "segk_bn_reduce": [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p],
+    "segk_bn_reduce": [c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p],
     "segk_bn_coeffs": [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p,
                        c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "segk_bn_coeffs_eval": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,

@@ -1,0 +1,505 @@
+"""autograd.Function wrappers that chain the C-ABI kernels into the head's training step.
+
+Data flow (all intermediate activations pixel-major [pixels, channels], dtype = config.compute_dtype()):
+
+  ASPPFunction     x[N,Cin,h,w] -> 4 conv branches + pooled branch written straight into the slices of one
+                   [M,5P] buffer -> 1x1 projection -> BN -> ReLU -> dropout                (modeling/aspp.py:131-147)
+  DecoderFunction  low-level 1x1 + BN + ReLU and the upsampled ASPP output written into one [M,304(+16 zero)]
+                   buffer -> 3x3 -> 3x3 -> classifier                                       (modeling/decoder.py:171-180)
+  UpsampleFunction pixel-major logits -> NCHW fp32 at input size                            (modeling/deeplab.py:252)
+  CrossEntropyFunction fused log-softmax + NLL with ignore index                            (utils/loss.py:23-35)
+  SyncBNFunction   stand-alone batch norm for the feeder's layers                           (sync_batchnorm/batchnorm.py:48-78)
+
+Every conv->BN->ReLU(->dropout) unit is: implicit-GEMM conv that also emits per-tile sum / sum-of-squares,
+a tiny reduce (+ all-reduce across ranks), coefficient kernel, one fused apply pass.  Backward mirrors it:
+reduce pass (sum g, sum g*xhat) (+ all-reduce), apply pass, weight-gradient GEMM, data-gradient GEMM.
+"""
+import torch
+
+from . import config, ops, parallel
+from ._lib import NCHW, PM
+
+_BN_TYPES = (torch.nn.modules.batchnorm._BatchNorm,)
+
+# Test hook: when set to a list, every fused conv->BN->ReLU unit appends (output view, (N,H,W)) so a test can
+# read the activation pattern the kernels produced.  None in normal operation.
+CAPTURE = None
+
+
+# ------------------------------------------------------------------ views ----
+def pm_view_of(t):
+    """2-D pixel-major view [N*H*W, C] of a 4-D tensor whose memory already is pixel-major
+    (channels_last tensors, or views handed out by this module); None otherwise."""
+    if t.dim() != 4:
+        return None
+    N, C, H, W = t.shape
+    s = t.stride()
+    if C > 1 and s[1] != 1:
+        return None
+    if W > 1:
+        ld = s[3]
+    elif H > 1:
+        ld = s[2]
+    elif N > 1:
+        ld = s[0]
+    else:
+        ld = C
+    if ld < C:
+        return None
+    if (W > 1 and s[3] != ld) or (H > 1 and s[2] != W * ld) or (N > 1 and s[0] != H * W * ld):
+        return None
+    return torch.as_strided(t, (N * H * W, C), (ld, 1), t.storage_offset())
+
+
+def nchw_view_of(v, N, H, W):
+    """NCHW-shaped strided view of a pixel-major 2-D view (no copy)."""
+    ld, C = v.stride(0), v.shape[1]
+    return torch.as_strided(v, (N, C, H, W), (H * W * ld, 1, W * ld, ld), v.storage_offset())
+
+
+def to_pm(t, dtype):
+    """Pixel-major [M, C] tensor of `dtype` holding the 4-D tensor t (view when possible, else one
+    transposing kernel)."""
+    v = pm_view_of(t)
+    if v is not None and v.dtype == dtype:
+        return v
+    N, C, H, W = t.shape
+    if v is not None:
+        out = torch.empty((N * H * W, C), dtype=dtype, device=t.device)
+        out.copy_(v)
+        return out
+    src = t
+    if src.dtype != torch.float32 or not src.is_contiguous():
+        src = src.float().contiguous()
+    out = torch.empty((N * H * W, C), dtype=dtype, device=t.device)
+    return ops.nchw_to_pm(src, out)
+
+
+def grad_like(input_tensor, g_pm, N, H, W):
+    """Gradient for `input_tensor` from a pixel-major gradient: a strided NCHW view when the input was
+    pixel-major memory of the same dtype, otherwise a contiguous NCHW tensor of the input's dtype."""
+    if pm_view_of(input_tensor) is not None and g_pm.dtype == input_tensor.dtype:
+        return nchw_view_of(g_pm, N, H, W)
+    out = ops.pm_to_nchw(g_pm, N, H, W)
+    return out if input_tensor.dtype == torch.float32 else out.to(input_tensor.dtype)
+
+
+# --------------------------------------------------------------- BN helper ----
+class _BNSpec:
+    """What a batch-norm module contributes to a fused unit."""
+
+    def __init__(self, bn):
+        if not isinstance(bn, _BN_TYPES):
+            raise TypeError("expected a batch-norm module, got %r" % type(bn))
+        if bn.momentum is None:
+            raise NotImplementedError("cumulative-average batch norm (momentum=None) is not on this path")
+        self.eps = float(bn.eps)
+        self.momentum = float(bn.momentum)
+        self.training = bool(bn.training) or bn.running_mean is None
+        self.running_mean = bn.running_mean
+        self.running_var = bn.running_var
+        from .modeling.sync_batchnorm.batchnorm import _SynchronizedBatchNorm
+        self.sync = isinstance(bn, _SynchronizedBatchNorm) and parallel.is_distributed()
+
+
+def _global_sums(local, sync):
+    if sync:
+        g = local.clone()
+        parallel.all_reduce_sum_(g)
+        return g
+    return local
+
+
+def _check_count(sums_host_count):
+    if sums_host_count <= 1:
+        raise ValueError("Expected more than 1 value per channel when training (batch-norm statistics)")
+
+
+class _UnitRecord:
+    __slots__ = ("x", "raw", "coef", "mask", "mask_scale", "relu", "training", "sync", "geom", "R", "dil", "Cout",
+                 "Cin", "weight")
+
+
+def _dropout_mask(shape, p, device):
+    if p <= 0.0:
+        return None, 1.0
+    if p >= 1.0:
+        return torch.zeros(shape, dtype=torch.uint8, device=device), 0.0
+    keep = torch.rand(shape, device=device) >= p
+    return keep.to(torch.uint8), 1.0 / (1.0 - p)
+
+
+def unit_forward(x, weight, R, dil, geom, spec, gamma, beta, out, relu=True, drop_p=0.0, drop_training=True):
+    """conv(x) -> BN -> ReLU -> dropout into `out` (a pixel-major view).  x: [M, >=Ck] view whose padding
+    channels are zero.  Returns the record the backward needs."""
+    N, H, W = geom
+    M = N * H * W
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    cd = x.dtype
+    wp = ops.pack_weight(weight.detach(), cd)
+    # the pre-normalisation output stays fp32 (the accumulator's precision): statistics and the normalised
+    # values then refer to the same numbers, and bf16 mode rounds once per layer instead of twice
+    raw = torch.empty((M, Cout), dtype=torch.float32, device=x.device)
+    stats = ops.conv_fwd([(x, wp, R, dil)], N, H, W, Cout, raw, want_stats=spec.training)
+    if spec.training:
+        local = ops.bn_reduce(stats, float(M))
+        total = M * (parallel.world_size() if spec.sync else 1)
+        _check_count(total)
+        sums = _global_sums(local, spec.sync)
+        coef = ops.bn_coeffs(sums, gamma, beta, spec.eps, spec.momentum, spec.running_mean, spec.running_var,
+                             legacy_clamp=config.legacy_clamp_eps() and spec.sync)
+    else:
+        coef = ops.bn_coeffs_eval(spec.running_mean, spec.running_var, gamma, beta, spec.eps)
+    mask, mask_scale = (None, 1.0)
+    if drop_training and drop_p > 0.0:
+        mask, mask_scale = _dropout_mask((M, Cout), drop_p, x.device)
+    ops.bn_apply(raw, out, coef, PM, relu, mask, mask_scale)
+    if CAPTURE is not None:
+        CAPTURE.append((out, geom))
+    rec = _UnitRecord()
+    rec.x, rec.raw, rec.coef, rec.mask, rec.mask_scale = x, raw, coef, mask, mask_scale
+    rec.relu, rec.training, rec.sync, rec.geom = relu, spec.training, spec.sync, geom
+    rec.R, rec.dil, rec.Cout, rec.Cin, rec.weight = R, dil, Cout, Cin, weight
+    return rec
+
+
+def unit_backward(rec, dz, need_dw=True):
+    """dz: pixel-major gradient w.r.t. the unit's output.  Returns (dy [M, Cout rounded up to 32] with zero
+    padding = gradient w.r.t. the conv output, dW, dgamma, dbeta)."""
+    N, H, W = rec.geom
+    M = N * H * W
+    C = rec.Cout
+    local = ops.bn_bwd_local_sums(dz, rec.raw, rec.coef, PM, rec.relu, rec.mask, rec.mask_scale)
+    dbeta, dgamma = local[:C].float(), local[C:2 * C].float()
+    gs = _global_sums(local, rec.sync and rec.training)
+    cpad = ops.round_up(C, 32)
+    alloc = torch.zeros if cpad != C else torch.empty
+    dy = alloc((M, cpad), dtype=dz.dtype, device=dz.device)
+    ops.bn_bwd_apply(dz, rec.raw, dy[:, :C] if cpad != C else dy, rec.coef, gs, PM, rec.relu, rec.mask, rec.mask_scale,
+                     eval_mode=not rec.training)
+    dw = None
+    if need_dw:
+        c16 = ops.round_up(C, 16)
+        dw = ops.conv_wgrad(rec.x, dy[:, :c16] if c16 != cpad else dy, N, H, W, rec.R, rec.dil, C, rec.Cin)
+    return dy, dw, dgamma, dbeta
+
+
+def dgrad(items, geom, Cin, out_dtype, img_bias=None):
+    """Data gradient of one or several convolutions that share their input: items = [(dy, weight, R, dil)].
+    Returns a pixel-major [M, Cin rounded up to 4] tensor of out_dtype."""
+    N, H, W = geom
+    segs = []
+    for dy, weight, R, dil in items:
+        segs.append((dy, ops.pack_weight(weight.detach(), dy.dtype, transpose=True), R, dil))
+    cpad = ops.round_up(Cin, 4)
+    out = torch.empty((N * H * W, cpad), dtype=out_dtype, device=items[0][0].device)
+    ops.conv_fwd(segs, N, H, W, Cin, out, img_bias=img_bias)
+    return out[:, :Cin] if cpad != Cin else out
+
+
+def _padded_input(v, mult=32):
+    """Pixel-major tensor whose row length is a multiple of `mult` with zero padding (copy only if needed)."""
+    M, C = v.shape
+    if C % mult == 0:
+        return v
+    buf = torch.zeros((M, ops.round_up(C, mult)), dtype=v.dtype, device=v.device)
+    buf[:, :C].copy_(v)
+    return buf
+
+
+# ------------------------------------------------------------ ASPP branch ----
+class BranchFunction(torch.autograd.Function):
+    """One `_ASPPModule`: conv -> BN -> ReLU (modeling/aspp.py:17-21)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, mod):
+        cd = config.compute_dtype()
+        N, _, H, W = x.shape
+        conv = mod.atrous_conv
+        R, dil = conv.kernel_size[0], conv.dilation[0]
+        xp = _padded_input(to_pm(x, cd))
+        out = torch.empty((N * H * W, weight.shape[0]), dtype=cd, device=x.device)
+        rec = unit_forward(xp, weight, R, dil, (N, H, W), _BNSpec(mod.bn), gamma, beta, out, relu=True)
+        ctx.rec, ctx.x = rec, x
+        return nchw_view_of(out, N, H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        rec, x = ctx.rec, ctx.x
+        N, H, W = rec.geom
+        dy, dw, dgamma, dbeta = unit_backward(rec, to_pm(g, rec.x.dtype))
+        dxp = dgrad([(dy, rec.weight, rec.R, rec.dil)], rec.geom, rec.Cin, torch.float32)
+        return grad_like(x, dxp, N, H, W), dw, dgamma, dbeta, None
+
+
+# ------------------------------------------------------------------- ASPP ----
+class ASPPFunction(torch.autograd.Function):
+    """Parameters arrive flat: x, then for each of aspp1..4, pool, proj: (conv weight, gamma, beta)."""
+
+    @staticmethod
+    def forward(ctx, mod, x, *params):
+        cd = config.compute_dtype()
+        N, Cin, H, W = x.shape
+        M = N * H * W
+        geom = (N, H, W)
+        branches = [mod.aspp1, mod.aspp2, mod.aspp3, mod.aspp4]
+        P = mod.conv1.out_channels
+        xp = _padded_input(to_pm(x, cd))
+        cat = torch.empty((M, 5 * P), dtype=cd, device=x.device)
+        recs = []
+        for b, br in enumerate(branches):
+            w, g, be = params[3 * b:3 * b + 3]
+            conv = br.atrous_conv
+            recs.append(unit_forward(xp, w, conv.kernel_size[0], conv.dilation[0], geom, _BNSpec(br.bn), g, be,
+                                     cat[:, b * P:(b + 1) * P], relu=True))
+        # image-pooling branch: mean over pixels -> 1x1 conv -> BN -> ReLU -> broadcast
+        w, g, be = params[12:15]
+        # (kept in fp32 whatever the compute dtype: N rows only, and its batch norm sees just N samples per
+        # channel, which amplifies operand rounding)
+        pooled = _padded_input(ops.pool_sum(xp, N, H * W, 1.0 / (H * W)))
+        p5 = torch.empty((N, P), dtype=torch.float32, device=x.device)
+        rec5 = unit_forward(pooled, w, 1, 1, (N, 1, 1), _BNSpec(mod.global_avg_pool[2]), g, be, p5, relu=True)
+        ops.upsample_fwd(p5, N, P, 1, 1, cat[:, 4 * P:5 * P], H, W, PM)
+        # projection
+        w, g, be = params[15:18]
+        out = torch.empty((M, P), dtype=cd, device=x.device)
+        recp = unit_forward(cat, w, 1, 1, geom, _BNSpec(mod.bn1), g, be, out, relu=True, drop_p=mod.dropout.p,
+                            drop_training=mod.dropout.training)
+        ctx.recs, ctx.rec5, ctx.recp, ctx.x, ctx.P, ctx.geom = recs, rec5, recp, x, P, geom
+        return nchw_view_of(out, N, H, W)
+
+    @staticmethod
+    def backward(ctx, gout):
+        recs, rec5, recp, x, P = ctx.recs, ctx.rec5, ctx.recp, ctx.x, ctx.P
+        N, H, W = ctx.geom
+        cd = recp.x.dtype
+        grads = [None] * 18
+        dyp, dwp, dgp, dbp = unit_backward(recp, to_pm(gout, cd))
+        grads[15:18] = [dwp, dgp, dbp]
+        dcat = dgrad([(dyp, recp.weight, 1, 1)], ctx.geom, 5 * P, cd)
+        # pooled branch: adjoint of the broadcast is a sum over pixels
+        d5 = ops.pool_sum(dcat[:, 4 * P:5 * P], N, H * W, 1.0)
+        dy5, dw5, dg5, db5 = unit_backward(rec5, d5)
+        grads[12:15] = [dw5, dg5, db5]
+        dpooled = dgrad([(dy5, rec5.weight, 1, 1)], (N, 1, 1), rec5.Cin, torch.float32)
+        img_bias = (dpooled * (1.0 / (H * W))).contiguous()
+        items = []
+        for b, rec in enumerate(recs):
+            dy, dw, dg, db = unit_backward(rec, dcat[:, b * P:(b + 1) * P])
+            grads[3 * b:3 * b + 3] = [dw, dg, db]
+            items.append((dy, rec.weight, rec.R, rec.dil))
+        if ctx.needs_input_grad[1]:
+            dxp = dgrad(items, ctx.geom, recs[0].Cin, torch.float32, img_bias=img_bias)
+            dx = grad_like(x, dxp, N, H, W)
+        else:
+            dx = None
+        return (None, dx) + tuple(grads)
+
+
+# ---------------------------------------------------------------- Decoder ----
+class DecoderFunction(torch.autograd.Function):
+    """params: conv1.w, bn1.g, bn1.b, last0.w, last1.g, last1.b, last4.w, last5.g, last5.b, last8.w, last8.b"""
+
+    @staticmethod
+    def forward(ctx, mod, x, low, *params):
+        cd = config.compute_dtype()
+        N, Cx, h, w = x.shape
+        _, Cl, H, W = low.shape
+        M = N * H * W
+        geom = (N, H, W)
+        lc = mod.last_conv
+        C48 = mod.conv1.out_channels
+        Ccat = Cx + C48
+        Ck = ops.round_up(Ccat, 32)
+        cat = torch.empty((M, Ck), dtype=cd, device=x.device)
+        if Ck != Ccat:
+            cat[:, Ccat:].zero_()
+        xp = to_pm(x, cd)
+        ops.upsample_fwd(xp, N, Cx, h, w, cat[:, :Cx], H, W, PM)
+        lowp = _padded_input(to_pm(low, cd))
+        rec1 = unit_forward(lowp, params[0], 1, 1, geom, _BNSpec(mod.bn1), params[1], params[2], cat[:, Cx:Ccat],
+                            relu=True)
+        P = lc[0].out_channels
+        a1 = torch.empty((M, P), dtype=cd, device=x.device)
+        recA = unit_forward(cat, params[3], 3, lc[0].dilation[0], geom, _BNSpec(lc[1]), params[4], params[5], a1,
+                            relu=True, drop_p=lc[3].p, drop_training=lc[3].training)
+        a2 = torch.empty((M, lc[4].out_channels), dtype=cd, device=x.device)
+        recB = unit_forward(a1, params[6], 3, lc[4].dilation[0], geom, _BNSpec(lc[5]), params[7], params[8], a2,
+                            relu=True, drop_p=lc[7].p, drop_training=lc[7].training)
+        K = lc[8].out_channels
+        Kpad = ops.round_up(K, 32)
+        logits = torch.zeros((M, Kpad), dtype=torch.float32, device=x.device)  # small: keep the scores fp32
+        bias = params[10]
+        a2p = _padded_input(a2)
+        ops.conv_fwd([(a2p, ops.pack_weight(params[9].detach(), cd), 1, 1)], N, H, W, K,
+                     logits[:, :ops.round_up(K, 4)], bias=None if bias is None else bias.detach().float().contiguous())
+        ctx.rec1, ctx.recA, ctx.recB, ctx.a2p = rec1, recA, recB, a2p
+        ctx.x, ctx.low, ctx.geom, ctx.hw, ctx.K, ctx.Cx, ctx.wcls = x, low, geom, (h, w), K, Cx, params[9]
+        ctx.has_bias = bias is not None
+        return nchw_view_of(logits[:, :K], N, H, W)
+
+    @staticmethod
+    def backward(ctx, gout):
+        rec1, recA, recB = ctx.rec1, ctx.recA, ctx.recB
+        N, H, W = ctx.geom
+        h, w = ctx.hw
+        K, Cx = ctx.K, ctx.Cx
+        cd = recA.x.dtype
+        M = N * H * W
+        Kpad = ops.round_up(K, 32)
+        # own zero-padded copy of the incoming gradient (its padding is not ours to trust)
+        gv = pm_view_of(gout)
+        dyc = torch.zeros((M, Kpad), dtype=cd, device=gout.device)
+        if gv is not None:
+            dyc[:, :K].copy_(gv)
+        else:
+            ops.nchw_to_pm(gout.float().contiguous(), dyc[:, :K])
+        Pb = recB.Cout
+        dw8 = ops.conv_wgrad(ctx.a2p, dyc, N, H, W, 1, 1, K, Pb)
+        db8 = ops.bn_local_sums(dyc, PM)[:K].float() if ctx.has_bias else None
+        da2 = dgrad([(dyc, ctx.wcls, 1, 1)], ctx.geom, Pb, cd)
+        dyB, dwB, dgB, dbB = unit_backward(recB, da2)
+        da1 = dgrad([(dyB, recB.weight, recB.R, recB.dil)], ctx.geom, recB.Cin, cd)
+        dyA, dwA, dgA, dbA = unit_backward(recA, da1)
+        Ccat = recA.Cin
+        dcat = dgrad([(dyA, recA.weight, recA.R, recA.dil)], ctx.geom, Ccat, cd)
+        dy1, dw1, dg1, db1 = unit_backward(rec1, dcat[:, Cx:Ccat])
+        dlow = dx = None
+        if ctx.needs_input_grad[2]:
+            dlowp = dgrad([(dy1, rec1.weight, 1, 1)], ctx.geom, rec1.Cin, torch.float32)
+            dlow = grad_like(ctx.low, dlowp, N, H, W)
+        if ctx.needs_input_grad[1]:
+            dxp = torch.empty((N * h * w, Cx), dtype=cd, device=gout.device)
+            ops.upsample_bwd(dcat[:, :Cx], PM, N, Cx, H, W, dxp, Cx, h, w)
+            if pm_view_of(ctx.x) is not None and ctx.x.dtype == cd:
+                dx = nchw_view_of(dxp, N, h, w)
+            else:
+                dx = ops.pm_to_nchw(dxp, N, h, w).to(ctx.x.dtype)
+        return (None, dx, dlow, dw1, dg1, db1, dwA, dgA, dbA, dwB, dgB, dbB, dw8, db8)
+
+
+# --------------------------------------------------------------- upsample ----
+class UpsampleFunction(torch.autograd.Function):
+    """F.interpolate(x, size, mode='bilinear', align_corners=True) -> contiguous NCHW fp32."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        N, C, Hi, Wi = x.shape
+        Ho, Wo = int(size[0]), int(size[1])
+        v = pm_view_of(x)
+        if v is None or v.stride(0) % 4 != 0 or v.stride(0) < ops.round_up(C, 4) or v.data_ptr() % 16 != 0:
+            buf = torch.zeros((N * Hi * Wi, ops.round_up(C, 4)), dtype=x.dtype if x.dtype == torch.bfloat16 else torch.float32,
+                              device=x.device)
+            src = v if v is not None else to_pm(x, buf.dtype)
+            buf[:, :C].copy_(src)
+            v = buf[:, :C]
+        out = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device)
+        ops.upsample_fwd(v, N, C, Hi, Wi, out, Ho, Wo, NCHW)
+        ctx.x, ctx.dims, ctx.gdtype = x, (N, C, Hi, Wi, Ho, Wo), v.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, Hi, Wi, Ho, Wo = ctx.dims
+        cpad = ops.round_up(C, 32)
+        din = torch.empty((N * Hi * Wi, cpad), dtype=ctx.gdtype, device=g.device)
+        ops.upsample_bwd(g.float().contiguous(), NCHW, N, C, Ho, Wo, din, cpad, Hi, Wi)
+        x = ctx.x
+        if pm_view_of(x) is not None and x.dtype == din.dtype:
+            return nchw_view_of(din[:, :C], N, Hi, Wi), None
+        return ops.pm_to_nchw(din[:, :C], N, Hi, Wi).to(x.dtype), None
+
+
+def interpolate_bilinear_ac(x, size):
+    return UpsampleFunction.apply(x, size)
+
+
+# ------------------------------------------------------------------- loss ----
+class CrossEntropyFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logit, target, weight, ignore_index, size_average, batch_average):
+        lg = logit if (logit.dtype == torch.float32 and logit.is_contiguous()) else logit.float().contiguous()
+        tg = target if (target.dtype == torch.float32 and target.is_contiguous()) else target.float().contiguous()
+        n = lg.shape[0]
+        sums, lse = ops.ce_fwd(lg, tg, weight, ignore_index)
+        pack = torch.cat([sums, torch.full((1,), float(n), dtype=torch.float32, device=lg.device)])
+        parallel.all_reduce_sum_(pack)  # global {sum w*nll, sum w, batch}
+        denom = torch.ones((), dtype=torch.float32, device=lg.device)
+        if size_average:
+            denom = denom * pack[1]
+        if batch_average:
+            denom = denom * pack[2]
+        ctx.saved = (lg, tg, weight, lse, denom, ignore_index, logit.dtype)
+        return pack[0] / denom
+
+    @staticmethod
+    def backward(ctx, g):
+        lg, tg, weight, lse, denom, ignore_index, dt = ctx.saved
+        coef = (g.float() / denom).reshape(1).contiguous()
+        dl = ops.ce_bwd(lg, tg, weight, lse, ignore_index, coef)
+        return (dl if dt == torch.float32 else dl.to(dt)), None, None, None, None, None
+
+
+def cross_entropy(logit, target, weight=None, ignore_index=255, size_average=True, batch_average=True):
+    return CrossEntropyFunction.apply(logit, target, weight, ignore_index, size_average, batch_average)
+
+
+# ----------------------------------------------------------------- SyncBN ----
+class SyncBNFunction(torch.autograd.Function):
+    """Stand-alone batch norm on NCHW (or channels_last) tensors: the feeder's layers."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mod):
+        spec = _BNSpec(mod)
+        layout, xv, shape = NCHW, x, x.shape
+        v = pm_view_of(x) if x.dim() == 4 else None
+        if v is not None and not x.is_contiguous() and v.shape[1] % 4 == 0:
+            layout, xv = PM, v
+        elif not x.is_contiguous():
+            xv = x.contiguous()
+        if xv.dtype not in (torch.float32, torch.bfloat16):
+            xv = xv.float()
+        C = shape[1]
+        count = x.numel() // C
+        if spec.training:
+            local = ops.bn_local_sums(xv, layout)
+            _check_count(count * (parallel.world_size() if spec.sync else 1))
+            sums = _global_sums(local, spec.sync)
+            coef = ops.bn_coeffs(sums, gamma, beta, spec.eps, spec.momentum, spec.running_mean, spec.running_var,
+                                 legacy_clamp=config.legacy_clamp_eps() and spec.sync)
+        else:
+            coef = ops.bn_coeffs_eval(spec.running_mean, spec.running_var, gamma, beta, spec.eps)
+        if layout == PM:
+            y = torch.empty_like(x, memory_format=torch.channels_last)
+            ops.bn_apply(xv, pm_view_of(y), coef, PM, False)
+        else:
+            y = torch.empty_like(xv)
+            ops.bn_apply(xv, y, coef, NCHW, False)
+        ctx.saved = (xv, coef, layout, spec.training, spec.sync, x.dtype, shape)
+        ctx.affine = gamma is not None
+        return y if y.dtype == x.dtype else y.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        xv, coef, layout, training, sync, in_dtype, shape = ctx.saved
+        C = shape[1]
+        if layout == PM:
+            gv = pm_view_of(g)
+            if gv is None or gv.dtype != xv.dtype:
+                gc = g.to(xv.dtype).contiguous(memory_format=torch.channels_last)
+                gv = pm_view_of(gc)
+            dx = torch.empty(shape, dtype=xv.dtype, device=g.device, memory_format=torch.channels_last)
+            dxv = pm_view_of(dx)
+        else:
+            gv = g.to(xv.dtype).contiguous()
+            dx = torch.empty_like(xv)
+            dxv = dx
+        local = ops.bn_bwd_local_sums(gv, xv, coef, layout, False)
+        dbeta, dgamma = local[:C].float(), local[C:2 * C].float()
+        gs = _global_sums(local, sync and training)
+        ops.bn_bwd_apply(gv, xv, dxv, coef, gs, layout, False, eval_mode=not training)
+        if dx.dtype != in_dtype:
+            dx = dx.to(in_dtype)
+        if not ctx.affine:
+            dgamma = dbeta = None
+        return dx, dgamma, dbeta, None

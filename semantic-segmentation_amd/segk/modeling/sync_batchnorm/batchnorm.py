@@ -1,0 +1,48 @@
+"""SynchronizedBatchNorm{1,2,3}d on HIP kernels, one process per GPU.
+
+Replaces /root/reference/modeling/sync_batchnorm/batchnorm.py:38-126: constructor signature, class
+hierarchy (subclass of torch's _BatchNorm, not of nn.BatchNorm2d), parameters and buffers are the
+same, so state_dicts interchange.  Statistics are global over all ranks of the default process group:
+each rank reduces sum / sum-of-squares of its shard with a HIP kernel, one all-reduce of a [2C+1] fp32
+vector replaces the master/slave queue hand-off (comm.py:97-125) plus ReduceAddCoalesced/Broadcast
+(batchnorm.py:101-105), and every rank derives mean, inv_std and the running statistics itself.  With a
+single rank, or in eval mode, the arithmetic is F.batch_norm's (batchnorm.py:50-53).
+"""
+from torch.nn.modules.batchnorm import _BatchNorm
+
+from ... import functional as SF
+
+__all__ = ["SynchronizedBatchNorm1d", "SynchronizedBatchNorm2d", "SynchronizedBatchNorm3d"]
+
+
+class _SynchronizedBatchNorm(_BatchNorm):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True):
+        super().__init__(num_features, eps=eps, momentum=momentum, affine=affine)
+
+    def forward(self, input):
+        self._check_input_dim(input)
+        if input.shape[1] != self.num_features:
+            raise ValueError("expected %d channels, got %d" % (self.num_features, input.shape[1]))
+        return SF.SyncBNFunction.apply(input, self.weight, self.bias, self)
+
+    def __data_parallel_replicate__(self, ctx, copy_id):
+        raise RuntimeError("this SynchronizedBatchNorm runs one process per GPU (torch.distributed); "
+                           "nn.DataParallel replication is not supported")
+
+
+class SynchronizedBatchNorm1d(_SynchronizedBatchNorm):
+    def _check_input_dim(self, input):
+        if input.dim() != 2 and input.dim() != 3:
+            raise ValueError("expected 2D or 3D input (got {}D input)".format(input.dim()))
+
+
+class SynchronizedBatchNorm2d(_SynchronizedBatchNorm):
+    def _check_input_dim(self, input):
+        if input.dim() != 4:
+            raise ValueError("expected 4D input (got {}D input)".format(input.dim()))
+
+
+class SynchronizedBatchNorm3d(_SynchronizedBatchNorm):
+    def _check_input_dim(self, input):
+        if input.dim() != 5:
+            raise ValueError("expected 5D input (got {}D input)".format(input.dim()))

@@ -123,7 +123,7 @@ def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=Fals
     stats = None
     if want_stats:
         rows = call("segk_conv_stat_rows", ctypes.byref(a))
-        stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=out.device)
+        stats = torch.empty((rows, 2, Cout), dtype=torch.float64, device=out.device)
         a.stat_partials = stats.data_ptr()
     else:
         a.stat_partials = None
@@ -175,25 +175,30 @@ def _bn_geom(x, layout):
 
 
 def bn_local_sums(x, layout):
-    """[2C+1] float32: per-channel sum, sum of squares, element count of THIS rank's tensor."""
+    """[2C+1] float64: per-channel sum, sum of squares, element count of THIS rank's tensor."""
     _dev(x)
     N, C, HW, ld = _bn_geom(x, layout)
     rows = call("segk_bn_stat_rows", layout, N, C, HW)
-    partials = torch.empty((rows, 2, C), dtype=torch.float32, device=x.device)
+    partials = torch.empty((rows, 2, C), dtype=torch.float64, device=x.device)
     call("segk_bn_stats", _ptr(x), _dt(x), layout, N, C, HW, ld, _ptr(partials), _stream())
     return bn_reduce(partials, float(N * HW))
 
 
 def bn_reduce(partials, count):
+    """[rows, 2, C] float64 partial rows -> [2C+1] float64 (two per-channel sums, then the count)."""
     rows, two, C = partials.shape
-    sums = torch.empty((2 * C + 1,), dtype=torch.float32, device=partials.device)
-    call("segk_bn_reduce", _ptr(partials), rows, C, ctypes.c_float(count), _ptr(sums), _stream())
+    if partials.dtype != torch.float64 or not partials.is_contiguous():
+        raise ValueError("statistic partials are contiguous float64")
+    sums = torch.empty((2 * C + 1,), dtype=torch.float64, device=partials.device)
+    call("segk_bn_reduce", _ptr(partials), rows, C, ctypes.c_double(count), _ptr(sums), _stream())
     return sums
 
 
 def bn_coeffs(sums, gamma, beta, eps, momentum, running_mean, running_var, legacy_clamp=False):
     """-> coef [4, C] float32 rows: mean, inv_std, scale, shift; running statistics updated in place."""
     C = (sums.numel() - 1) // 2
+    if sums.dtype != torch.float64:
+        raise ValueError("batch-norm sums are float64")
     coef = torch.empty((4, C), dtype=torch.float32, device=sums.device)
     _dev(sums, gamma, beta, running_mean, running_var)
     call("segk_bn_coeffs", _ptr(sums), _ptr(gamma), _ptr(beta), ctypes.c_float(eps), ctypes.c_float(momentum),
@@ -232,7 +237,7 @@ def bn_apply(x, y, coef, layout, relu, mask=None, mask_scale=1.0):
 
 
 def bn_bwd_local_sums(dz, x, coef, layout, relu, mask=None, mask_scale=1.0):
-    """[2C+1] float32: sum g, sum g*xhat, count for this rank (g = dz through dropout and ReLU)."""
+    """[2C+1] float64: sum g, sum g*xhat, count for this rank (g = dz through dropout and ReLU)."""
     _dev(dz, x, coef)
     N, C, HW, x_ld = _bn_geom(x, layout)
     dz_ld = _pm(dz)[0] if layout == PM else 0
@@ -240,7 +245,7 @@ def bn_bwd_local_sums(dz, x, coef, layout, relu, mask=None, mask_scale=1.0):
         raise ValueError("NCHW gradient must be contiguous")
     _mask_check(mask, x)
     rows = call("segk_bn_stat_rows", layout, N, C, HW)
-    partials = torch.empty((rows, 2, C), dtype=torch.float32, device=x.device)
+    partials = torch.empty((rows, 2, C), dtype=torch.float64, device=x.device)
     call("segk_bn_bwd_stats", _ptr(dz), _dt(dz), dz_ld, _ptr(x), _dt(x), x_ld, layout, N, C, HW, _ptr(coef[0]),
          _ptr(coef[1]), _ptr(coef[2]), _ptr(coef[3]), 1 if relu else 0, _ptr(mask), ctypes.c_float(mask_scale),
          _ptr(partials), _stream())

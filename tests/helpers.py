@@ -28,6 +28,13 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / scale)
 
 
+def rel_l2(a, b):
+    """||a-b||_2 / ||b||_2."""
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
 def assert_dicts_close(got, want, tol, grad_tol=None, exact=(), skip=()):
     """Keys starting with 'train_d'/'eval_d'/'d' (gradients) use grad_tol."""
     bad = []

@@ -114,7 +114,7 @@ def test_conv_fwd_exact_integers(ops, case, dtype):
     assert torch.equal(got, ref)
     assert float(out[:, ops.round_up(Cout, 4):].abs().sum()) == 0
     s = stats.sum(0)
-    assert torch.equal(s[0], ref.sum((0, 2, 3))) and torch.equal(s[1], (ref * ref).sum((0, 2, 3)))
+    assert torch.equal(s[0], ref.double().sum((0, 2, 3))) and torch.equal(s[1], (ref.double() ** 2).sum((0, 2, 3)))
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
@@ -265,7 +265,7 @@ def test_bn_clamp_and_eval(ops):
     from segk._lib import NCHW
     want = load_golden("syncbn")
     C = 12
-    sums = torch.cat([T(want["sum"]), T(want["ssum"]), torch.tensor([6 * 5 * 7.0], device=DEV)])
+    sums = torch.cat([T(want["sum"]), T(want["ssum"]), torch.tensor([6 * 5 * 7.0], device=DEV)]).double()
     rm = T(gen.normal(20240607, "syncbn/rm", (C,), std=0.1))
     rv = T(gen.uniform(20240607, "syncbn/rv", (C,), 0.5, 1.5))
     coef = ops.bn_coeffs(sums, None, None, 1e-5, 0.1, rm, rv, legacy_clamp=True)
