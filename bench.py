@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train images/sec of DeepLabv3+ (ResNet-101 feeder, OS16, 21 classes, 513x513,
+batch 16 per GPU) with the segmentation head on the HIP kernels.
+
+  python bench.py --gpus N --steps K --warmup W          (N = 1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" is what the reference's trainer does per batch (/root/reference/tain_origin.py:124-147): poly-LR
+update, zero_grad, forward, cross-entropy (ignore 255), backward, [gradient all-reduce], SGD(momentum 0.9,
+wd 5e-4, 1x/10x groups).  Synthetic inputs are resident in HBM before the timed region.  Rank 0 prints
+ONE JSON line.  The `roofline` object is measured live with HIP events around every launch of the
+dominant kernel (the implicit-GEMM convolution) inside the timed steps; `cpu_baseline` is the oracle's
+plain-PyTorch restatement of the same step timed on this box's host cores (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "semantic-segmentation_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X bf16 MFMA, dense
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X fp32 MFMA
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--size", type=int, default=513)
+    ap.add_argument("--classes", type=int, default=21)
+    ap.add_argument("--out-stride", type=int, default=16)
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--feeder-fp32", action="store_true", help="run the PyTorch feeder in fp32 even in bf16 mode")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def synthetic_batch(batch, size, classes, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    image = torch.randn((batch, 3, size, size), generator=g)
+    target = torch.randint(0, classes, (batch, size, size), generator=g).float()
+    target[torch.rand((batch, size, size), generator=g) < 0.02] = 255.0
+    for sl in (np.s_[:, :10, :], np.s_[:, -10:, :], np.s_[:, :, :10], np.s_[:, :, -10:]):
+        target[sl] = 255.0
+    return image.to(device), target.to(device)
+
+
+def cpu_baseline(args):
+    """The oracle's restatement of the same training step (+ Evaluator) on the host cores."""
+    import torch.nn as nn
+    from oracle import head_ref, ops_ref
+    torch.manual_seed(1)
+    threads = torch.get_num_threads()
+    model = head_ref.RefDeepLab("resnet", args.out_stride, args.classes, nn.BatchNorm2d)
+    model.train()
+    g1, g10 = model.lr_groups()
+    opt = torch.optim.SGD([{"params": g1, "lr": 0.007}, {"params": g10, "lr": 0.07}], momentum=0.9, weight_decay=5e-4)
+    image, target = synthetic_batch(args.cpu_batch, args.size, args.classes, "cpu", 1)
+    ev = ops_ref.RefEvaluator(args.classes)
+
+    def step():
+        opt.zero_grad()
+        out = model(image)
+        loss = ops_ref.ce_loss(out, target)
+        loss.backward()
+        opt.step()
+        ev.add_batch(target.numpy(), ops_ref.predict(out.detach().numpy()))
+
+    step()
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    sec = float(np.median(times))
+    return {"value": args.cpu_batch / sec, "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "oracle (plain PyTorch fp32) DeepLabv3+ R101 OS%d K=%d batch %d %dx%d: 1 warm-up + 2 timed "
+                      "train steps incl. host argmax + confusion matrix, median %.2f s/step"
+                      % (args.out_stride, args.classes, args.cpu_batch, args.size, args.size, sec)}
+
+
+def main():
+    args = parse()
+    from segk import config, ops, parallel
+    from segk.modeling.deeplab import DeepLab
+    from segk.utils.loss import SegmentationLosses
+    from segk.utils.lr_scheduler import LR_Scheduler
+
+    rank, world = parallel.init_from_env()
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    cd = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    config.set_compute_dtype(cd)
+    feeder_amp = args.dtype == "bf16" and not args.feeder_fp32
+
+    torch.manual_seed(1)  # the reference's --seed default; identical initial weights on every rank
+    model = DeepLab(backbone="resnet", output_stride=args.out_stride, num_classes=args.classes,
+                    sync_bn=(world > 1)).to(dev)
+    model.train()
+    if feeder_amp:
+        model.backbone = model.backbone.to(memory_format=torch.channels_last)
+        feeder_fwd = model.backbone.forward
+
+        def amp_forward(x):
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                return feeder_fwd(x.contiguous(memory_format=torch.channels_last))
+        model.backbone.forward = amp_forward
+    opt = torch.optim.SGD([{"params": model.get_1x_lr_params(), "lr": 0.007},
+                           {"params": model.get_10x_lr_params(), "lr": 0.07}],
+                          momentum=0.9, weight_decay=5e-4, nesterov=False)
+    criterion = SegmentationLosses(weight=None, cuda=True).build_loss("ce")
+    scheduler = LR_Scheduler("poly", 0.007, 50, 1000, quiet=True)
+    buckets = parallel.GradientBuckets([p for g in opt.param_groups for p in g["params"]])
+    image, target = synthetic_batch(args.batch, args.size, args.classes, dev, 1 + rank)
+
+    def step(i):
+        scheduler(opt, i, 0, 0.0)
+        opt.zero_grad(set_to_none=True)
+        out = model(image)
+        loss = criterion(out, target)
+        loss.backward()
+        buckets.reduce()
+        opt.step()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    timer = None
+    if not args.no_kernel_timing:
+        timer = ops.KernelTimer()
+        ops.TIMER = timer
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER = None
+    final_loss = float(loss)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    if rank == 0:
+        images = world * args.batch * args.steps
+        line = {
+            "metric": "train images/sec @513x513 DeepLabv3+ OS16",
+            "value": images / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "DeepLabv3+ ResNet-101 OS%d, %d classes, %dx%d, batch %d/GPU: full train step "
+                                   "(feeder on PyTorch-ROCm %s, head on HIP kernels %s, CE ignore 255, SGD)"
+                                   % (args.out_stride, args.classes, args.size, args.size, args.batch,
+                                      "bf16 autocast channels_last" if feeder_amp else "fp32", args.dtype),
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world,
+                       "final_loss": final_loss},
+        }
+        if timer is not None:
+            summ = timer.summary()
+            dom = summ.get("conv_fwd_kernel")
+            if dom:
+                peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MATRIX_PEAK_TFLOPS
+                ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+                line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                                    "frac": ach / peak, "traffic": None, "kernel": "conv_fwd_kernel (implicit-GEMM "
+                                    "forward + data gradient, all %d launches of the timed steps)" % dom["launches"],
+                                    "avg_launch_ms": dom["avg_ms"],
+                                    "share_of_step": dom["ms"] / (1000.0 * elapsed)}
+            wg = summ.get("conv_wgrad_kernel")
+            if wg:
+                peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MATRIX_PEAK_TFLOPS
+                ach = wg["flops"] / (wg["ms"] * 1e-3) / 1e12
+                line["roofline_wgrad"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                                          "frac": ach / peak, "avg_launch_ms": wg["avg_ms"],
+                                          "share_of_step": wg["ms"] / (1000.0 * elapsed)}
+        if world == 1 and not args.no_cpu_baseline:
+            del model, opt, buckets
+            torch.cuda.empty_cache()
+            line["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -75,6 +75,14 @@ def to_pm(t, dtype):
     return ops.nchw_to_pm(src, out)
 
 
+def grad_dtype_for(input_tensor):
+    """dtype in which to produce the pixel-major gradient of an input: the input's own when its memory is
+    pixel-major (the gradient is then returned as a view, no extra pass), else fp32 for the NCHW transpose."""
+    if input_tensor.dtype in (torch.float32, torch.bfloat16) and pm_view_of(input_tensor) is not None:
+        return input_tensor.dtype
+    return torch.float32
+
+
 def grad_like(input_tensor, g_pm, N, H, W):
     """Gradient for `input_tensor` from a pixel-major gradient: a strided NCHW view when the input was
     pixel-major memory of the same dtype, otherwise a contiguous NCHW tensor of the input's dtype."""
@@ -140,7 +148,7 @@ def unit_forward(x, weight, R, dil, geom, spec, gamma, beta, out, relu=True, dro
     # the pre-normalisation output stays fp32 (the accumulator's precision): statistics and the normalised
     # values then refer to the same numbers, and bf16 mode rounds once per layer instead of twice
     raw = torch.empty((M, Cout), dtype=torch.float32, device=x.device)
-    stats = ops.conv_fwd([(x, wp, R, dil)], N, H, W, Cout, raw, want_stats=spec.training)
+    stats = ops.conv_fwd([(x, wp, R, dil)], N, H, W, Cout, raw, want_stats=spec.training, true_ck=[Cin])
     if spec.training:
         local = ops.bn_reduce(stats, float(M))
         total = M * (parallel.world_size() if spec.sync else 1)
@@ -193,7 +201,7 @@ def dgrad(items, geom, Cin, out_dtype, img_bias=None):
         segs.append((dy, ops.pack_weight(weight.detach(), dy.dtype, transpose=True), R, dil))
     cpad = ops.round_up(Cin, 4)
     out = torch.empty((N * H * W, cpad), dtype=out_dtype, device=items[0][0].device)
-    ops.conv_fwd(segs, N, H, W, Cin, out, img_bias=img_bias)
+    ops.conv_fwd(segs, N, H, W, Cin, out, img_bias=img_bias, true_ck=[it[1].shape[0] for it in items])
     return out[:, :Cin] if cpad != Cin else out
 
 
@@ -228,7 +236,7 @@ class BranchFunction(torch.autograd.Function):
         rec, x = ctx.rec, ctx.x
         N, H, W = rec.geom
         dy, dw, dgamma, dbeta = unit_backward(rec, to_pm(g, rec.x.dtype))
-        dxp = dgrad([(dy, rec.weight, rec.R, rec.dil)], rec.geom, rec.Cin, torch.float32)
+        dxp = dgrad([(dy, rec.weight, rec.R, rec.dil)], rec.geom, rec.Cin, grad_dtype_for(x))
         return grad_like(x, dxp, N, H, W), dw, dgamma, dbeta, None
 
 
@@ -289,7 +297,7 @@ class ASPPFunction(torch.autograd.Function):
             grads[3 * b:3 * b + 3] = [dw, dg, db]
             items.append((dy, rec.weight, rec.R, rec.dil))
         if ctx.needs_input_grad[1]:
-            dxp = dgrad(items, ctx.geom, recs[0].Cin, torch.float32, img_bias=img_bias)
+            dxp = dgrad(items, ctx.geom, recs[0].Cin, grad_dtype_for(x), img_bias=img_bias)
             dx = grad_like(x, dxp, N, H, W)
         else:
             dx = None
@@ -332,7 +340,8 @@ class DecoderFunction(torch.autograd.Function):
         bias = params[10]
         a2p = _padded_input(a2)
         ops.conv_fwd([(a2p, ops.pack_weight(params[9].detach(), cd), 1, 1)], N, H, W, K,
-                     logits[:, :ops.round_up(K, 4)], bias=None if bias is None else bias.detach().float().contiguous())
+                     logits[:, :ops.round_up(K, 4)], bias=None if bias is None else bias.detach().float().contiguous(),
+                     true_ck=[a2.shape[1]])
         ctx.rec1, ctx.recA, ctx.recB, ctx.a2p = rec1, recA, recB, a2p
         ctx.x, ctx.low, ctx.geom, ctx.hw, ctx.K, ctx.Cx, ctx.wcls = x, low, geom, (h, w), K, Cx, params[9]
         ctx.has_bias = bias is not None
@@ -366,7 +375,7 @@ class DecoderFunction(torch.autograd.Function):
         dy1, dw1, dg1, db1 = unit_backward(rec1, dcat[:, Cx:Ccat])
         dlow = dx = None
         if ctx.needs_input_grad[2]:
-            dlowp = dgrad([(dy1, rec1.weight, 1, 1)], ctx.geom, rec1.Cin, torch.float32)
+            dlowp = dgrad([(dy1, rec1.weight, 1, 1)], ctx.geom, rec1.Cin, grad_dtype_for(ctx.low))
             dlow = grad_like(ctx.low, dlowp, N, H, W)
         if ctx.needs_input_grad[1]:
             dxp = torch.empty((N * h * w, Cx), dtype=cd, device=gout.device)

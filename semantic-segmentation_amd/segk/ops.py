@@ -46,6 +46,37 @@ def round_up(a, b):
     return (a + b - 1) // b * b
 
 
+class KernelTimer:
+    """Optional HIP-event timing of individual launches on the current stream (bench.py's roofline figures).
+    Assign an instance to ops.TIMER; the convolution wrappers then bracket each launch with two events and
+    record its algorithmic FLOPs.  None (default) = no events are created."""
+
+    def __init__(self):
+        self.records = {}   # name -> list of (flops, start_event, end_event)
+
+    def start(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def stop(self, name, flops, start):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.records.setdefault(name, []).append((flops, start, e))
+
+    def summary(self):
+        """name -> dict(launches, flops (sum), ms (sum), avg_ms); call after torch.cuda.synchronize()."""
+        out = {}
+        for name, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for _, s, e in recs)
+            fl = sum(f for f, _, _ in recs)
+            out[name] = {"launches": len(recs), "flops": fl, "ms": ms, "avg_ms": ms / max(len(recs), 1)}
+        return out
+
+
+TIMER = None
+
+
 # ------------------------------------------------------------------ layout ----
 def nchw_to_pm(x, out):
     """x: [N,C,H,W] float32 contiguous -> out: pixel-major view [N*H*W, C]."""
@@ -84,10 +115,12 @@ def pack_weight(w, dtype, transpose=False):
 
 
 # -------------------------------------------------------------------- conv ----
-def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=False):
+def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=False, true_ck=None):
     """segs: list of (in_view [M, >=Ck], packed_w [taps, Cout, Ck], R, dil).  Writes `out` ([M, Cout'] view,
-    Cout' >= Cout rounded up to 4).  Returns the [rows, 2, Cout] statistic partials when want_stats."""
+    Cout' >= Cout rounded up to 4).  Returns the [rows, 2, Cout] statistic partials when want_stats.
+    true_ck: un-padded contracted channel counts per segment (only used for FLOP accounting)."""
     M = N * H * W
+    timer_ck = true_ck if true_ck is not None else [w.shape[2] for _, w, _, _ in segs]
     a = ConvArgs()
     a.N, a.H, a.W, a.Cout, a.nseg = N, H, W, Cout, len(segs)
     if not 1 <= len(segs) <= _lib.MAX_SEG:
@@ -127,7 +160,12 @@ def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=Fals
         a.stat_partials = stats.data_ptr()
     else:
         a.stat_partials = None
+    t0 = TIMER.start() if TIMER is not None else None
     call("segk_conv_fwd", ctypes.byref(a), _stream())
+    if t0 is not None:
+        # nominal FLOPs: every tap counted (also the ones that fall outside the image), padded channels not
+        fl = sum(2.0 * M * Cout * timer_ck[i] * segs[i][2] ** 2 for i in range(len(segs)))
+        TIMER.stop("conv_fwd_kernel", fl, t0)
     return stats
 
 
@@ -156,7 +194,10 @@ def conv_wgrad(x, dout, N, H, W, R, dil, Cout_true, Cin_true, splits=None):
     a.inp, a.in_ld, a.Cin = x.data_ptr(), in_ld, Cin
     a.dout, a.dout_ld, a.Cout = dout.data_ptr(), do_ld, Cout
     a.R, a.dil, a.splits, a.slabs = R, dil, splits, slabs.data_ptr()
+    t0 = TIMER.start() if TIMER is not None else None
     call("segk_conv_wgrad", ctypes.byref(a), _stream())
+    if t0 is not None:
+        TIMER.stop("conv_wgrad_kernel", 2.0 * M * Cout_true * Cin_true * R * R, t0)
     dw = torch.empty((Cout_true, Cin_true, R, R), dtype=torch.float32, device=x.device)
     call("segk_wgrad_finish", _ptr(slabs), splits, R, Cin, Cout, _ptr(dw), Cout_true, Cin_true, _stream())
     return dw
