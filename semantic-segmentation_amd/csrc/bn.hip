@@ -333,16 +333,31 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_nchw_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ void bn_reduce_kernel(const double* __restrict__ partials, int rows, int C, double count,
-                                 double* __restrict__ sums) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 2 * C) {
-    double s = 0.0;
-    for (int r = 0; r < rows; ++r) s += partials[(size_t)r * 2 * C + i];
-    sums[i] = s;
-  } else if (i == 2 * C) {
-    sums[i] = count;
+// Block = 16 columns x 16 row phases; each thread sums rows phase, phase+16, ... of its column, then the 16
+// phase sums of a column are added in phase order: a fixed summation order, independent of scheduling.
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const double* __restrict__ partials, int rows, int C,
+                                                         double count, double* __restrict__ sums) {
+  __shared__ double red[16][17];
+  const int col = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int ph = threadIdx.x >> 4;
+  const int n2 = 2 * C;
+  double s = 0.0;
+  if (col < n2) {
+#pragma unroll 4
+    for (int r = ph; r < rows; r += 16) s += partials[(size_t)r * n2 + col];
   }
+  red[ph][threadIdx.x & 15] = s;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int c = blockIdx.x * 16 + threadIdx.x;
+    if (c < n2) {
+      double t = 0.0;
+#pragma unroll
+      for (int p = 0; p < 16; ++p) t += red[p][threadIdx.x];
+      sums[c] = t;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) sums[n2] = count;
 }
 
 __global__ void bn_coeffs_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
@@ -473,7 +488,7 @@ extern "C" int segk_bn_stats(const void* x, int dtype, int layout, int N, int C,
 extern "C" int segk_bn_reduce(const double* partials, int rows, int C, double count, double* sums,
                               segk_stream_t stream) {
   SEGK_REQUIRE(partials && sums && rows > 0 && C > 0, "bn_reduce: bad arguments rows=%d C=%d", rows, C);
-  bn_reduce_kernel<<<ceil_div(2 * C + 1, 256), 256, 0, (hipStream_t)stream>>>(partials, rows, C, count, sums);
+  bn_reduce_kernel<<<ceil_div(2 * C, 16), 256, 0, (hipStream_t)stream>>>(partials, rows, C, count, sums);
   SEGK_CHECK_LAUNCH("bn_reduce");
   return SEGK_OK;
 }
