@@ -45,6 +45,13 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-miopen-benchmark", action="store_true",
+                    help="leave torch.backends.cudnn.benchmark off (MIOpen then picks the feeder's conv algorithms "
+                         "heuristically instead of timing them in the first step)")
+    ap.add_argument("--feeder-nchw", action="store_true", help="keep the feeder in NCHW memory format")
+    ap.add_argument("--sync-bn", choices=["auto", "on", "off"], default="auto",
+                    help="SynchronizedBatchNorm2d (HIP) in every layer; auto = only with more than one rank, as the "
+                         "reference's trainers decide (train.py:381-385)")
     return ap.parse_args()
 
 
@@ -109,17 +116,19 @@ def main():
     config.set_compute_dtype(cd)
     feeder_amp = args.dtype == "bf16" and not args.feeder_fp32
 
+    torch.backends.cudnn.benchmark = not args.no_miopen_benchmark
     torch.manual_seed(1)  # the reference's --seed default; identical initial weights on every rank
     model = DeepLab(backbone="resnet", output_stride=args.out_stride, num_classes=args.classes,
-                    sync_bn=(world > 1)).to(dev)
+                    sync_bn=(world > 1) if args.sync_bn == "auto" else (args.sync_bn == "on")).to(dev)
     model.train()
     if feeder_amp:
-        model.backbone = model.backbone.to(memory_format=torch.channels_last)
+        fmt = torch.contiguous_format if args.feeder_nchw else torch.channels_last
+        model.backbone = model.backbone.to(memory_format=fmt)
         feeder_fwd = model.backbone.forward
 
         def amp_forward(x):
             with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
-                return feeder_fwd(x.contiguous(memory_format=torch.channels_last))
+                return feeder_fwd(x.contiguous(memory_format=fmt))
         model.backbone.forward = amp_forward
     opt = torch.optim.SGD([{"params": model.get_1x_lr_params(), "lr": 0.007},
                            {"params": model.get_10x_lr_params(), "lr": 0.07}],

@@ -13,12 +13,27 @@ constexpr int BN_MAX_ROWS_NCHW = 32;
 template <typename T, int VEC>
 __device__ __forceinline__ void load_vec(const T* p, float (&v)[VEC]);
 template <>
+__device__ __forceinline__ void load_vec<float, 8>(const float* p, float (&v)[8]) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+  v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+template <>
 __device__ __forceinline__ void load_vec<float, 4>(const float* p, float (&v)[4]) {
   f32x4 t = *reinterpret_cast<const f32x4*>(p);
   v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
 }
 template <>
 __device__ __forceinline__ void load_vec<float, 1>(const float* p, float (&v)[1]) { v[0] = *p; }
+template <>
+__device__ __forceinline__ void load_vec<bf16_t, 8>(const bf16_t* p, float (&v)[8]) {
+  u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[2 * k] = __uint_as_float(t[k] << 16);
+    v[2 * k + 1] = __uint_as_float(t[k] & 0xffff0000u);
+  }
+}
 template <>
 __device__ __forceinline__ void load_vec<bf16_t, 4>(const bf16_t* p, float (&v)[4]) {
   u32x2 t = *reinterpret_cast<const u32x2*>(p);
@@ -31,12 +46,23 @@ __device__ __forceinline__ void load_vec<bf16_t, 1>(const bf16_t* p, float (&v)[
 template <typename T, int VEC>
 __device__ __forceinline__ void store_vec(T* p, const float (&v)[VEC]);
 template <>
+__device__ __forceinline__ void store_vec<float, 8>(float* p, const float (&v)[8]) {
+  f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+  *reinterpret_cast<f32x4*>(p) = a;
+  *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+template <>
 __device__ __forceinline__ void store_vec<float, 4>(float* p, const float (&v)[4]) {
   f32x4 t = {v[0], v[1], v[2], v[3]};
   *reinterpret_cast<f32x4*>(p) = t;
 }
 template <>
 __device__ __forceinline__ void store_vec<float, 1>(float* p, const float (&v)[1]) { *p = v[0]; }
+template <>
+__device__ __forceinline__ void store_vec<bf16_t, 8>(bf16_t* p, const float (&v)[8]) {
+  u32x4 t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+  *reinterpret_cast<u32x4*>(p) = t;
+}
 template <>
 __device__ __forceinline__ void store_vec<bf16_t, 4>(bf16_t* p, const float (&v)[4]) {
   u32x2 t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -48,6 +74,12 @@ __device__ __forceinline__ void store_vec<bf16_t, 1>(bf16_t* p, const float (&v)
 template <int VEC>
 __device__ __forceinline__ void load_mask(const uint8_t* p, float (&v)[VEC]);
 template <>
+__device__ __forceinline__ void load_mask<8>(const uint8_t* p, float (&v)[8]) {
+  u32x2 t = *reinterpret_cast<const u32x2*>(p);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = (float)((t[k >> 2] >> (8 * (k & 3))) & 0xff);
+}
+template <>
 __device__ __forceinline__ void load_mask<4>(const uint8_t* p, float (&v)[4]) {
   unsigned int t = *reinterpret_cast<const unsigned int*>(p);
   v[0] = (float)(t & 0xff); v[1] = (float)((t >> 8) & 0xff); v[2] = (float)((t >> 16) & 0xff); v[3] = (float)(t >> 24);
@@ -56,50 +88,82 @@ template <>
 __device__ __forceinline__ void load_mask<1>(const uint8_t* p, float (&v)[1]) { v[0] = (float)*p; }
 
 // ---------------------------------------------------------------------------------------------
-// Pixel-major kernels.  Thread t owns channel group (t % cg) and walks pixels (t / cg) + k*rpb.
+// Pixel-major kernels.  A block owns a contiguous pixel range (blockIdx.x) and a slab of up to
+// BN_THREADS*VEC channels (blockIdx.y).  Thread t owns channel group (t % cg) and walks the pixels
+// (t / cg) + k*rpb, four at a time so that several 16-byte loads are in flight per lane.
 // ---------------------------------------------------------------------------------------------
-struct PmGeom {
-  int cg;   // channel groups = C / VEC
-  int rpb;  // pixel rows handled per block iteration = BN_THREADS / cg (>= 1)
+struct PmThread {
+  int c_base, Cs, cg, rpb, cgi, pr;
+  long long m0, m1;
+  bool active;
 };
 
-// Combine the per-thread accumulators a[VEC], b[VEC] of all pixel rows of the block and write one partial row.
+template <int VEC>
+__device__ __forceinline__ PmThread pm_thread(int C, long long M) {
+  PmThread t;
+  const int slab = BN_THREADS * VEC;
+  t.c_base = blockIdx.y * slab;
+  t.Cs = C - t.c_base < slab ? C - t.c_base : slab;
+  t.cg = t.Cs / VEC;
+  t.rpb = BN_THREADS / t.cg;
+  t.cgi = threadIdx.x % t.cg;
+  t.pr = threadIdx.x / t.cg;
+  t.active = t.pr < t.rpb;
+  const long long per = (M + gridDim.x - 1) / gridDim.x;
+  t.m0 = (long long)blockIdx.x * per;
+  t.m1 = t.m0 + per < M ? t.m0 + per : M;
+  return t;
+}
+
+// Combine the per-thread accumulators of all pixel rows of the block and write one partial row.
 template <int VEC, typename ACC>
-__device__ __forceinline__ void block_reduce_pm(ACC (&a)[VEC], ACC (&b)[VEC], int C, PmGeom g, double* out_row) {
-  __shared__ ACC red[2 * BN_THREADS * 4];
-  const int cgi = threadIdx.x % g.cg, pr = threadIdx.x / g.cg;
-  const bool active = pr < g.rpb;
-  // layout red[pr][2][C]
-  if (active) {
+__device__ __forceinline__ void block_reduce_pm(ACC (&a)[VEC], ACC (&b)[VEC], const PmThread& t, double* out_row, int C) {
+  __shared__ ACC red[2 * BN_THREADS * 8];
+  const int Cs = t.Cs;
+  if (t.active) {  // layout red[pr][2][Cs]
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      red[(pr * 2 + 0) * C + cgi * VEC + j] = a[j];
-      red[(pr * 2 + 1) * C + cgi * VEC + j] = b[j];
+      red[(t.pr * 2 + 0) * Cs + t.cgi * VEC + j] = a[j];
+      red[(t.pr * 2 + 1) * Cs + t.cgi * VEC + j] = b[j];
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += BN_THREADS) {
+  for (int i = threadIdx.x; i < 2 * Cs; i += BN_THREADS) {
     double s = 0.0;
-    for (int r = 0; r < g.rpb; ++r) s += (double)red[r * 2 * C + i];
-    out_row[i] = s;
+    for (int r = 0; r < t.rpb; ++r) s += (double)red[r * 2 * Cs + i];
+    const int which = i / Cs, c = i - which * Cs;
+    out_row[which * C + t.c_base + c] = s;
   }
 }
 
 template <typename TX, int VEC>
 __global__ __launch_bounds__(BN_THREADS) void bn_stats_pm_kernel(const TX* __restrict__ x, int ld, long long M, int C,
-                                                                  PmGeom g, double* __restrict__ partials) {
-  const int cgi = threadIdx.x % g.cg, pr = threadIdx.x / g.cg;
+                                                                  double* __restrict__ partials) {
+  const PmThread t = pm_thread<VEC>(C, M);
   // fp64 accumulation: squares of fp32 values are exact in fp64, so E[x^2] - E[x]^2 loses nothing
   double a[VEC], b[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) a[j] = b[j] = 0.0;
-  const long long per = (M + gridDim.x - 1) / gridDim.x;
-  const long long m0 = (long long)blockIdx.x * per;
-  const long long m1 = m0 + per < M ? m0 + per : M;
-  if (pr < g.rpb) {
-    for (long long m = m0 + pr; m < m1; m += g.rpb) {
+  if (t.active) {
+    const TX* xp = x + t.c_base + t.cgi * VEC;
+    const long long step = t.rpb;
+    long long m = t.m0 + t.pr;
+    for (; m + 3 * step < t.m1; m += 4 * step) {
+      float v[4][VEC];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) load_vec<TX, VEC>(xp + (m + k * step) * ld, v[k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const double d = (double)v[k][j];
+          a[j] += d;
+          b[j] = fma(d, d, b[j]);
+        }
+    }
+    for (; m < t.m1; m += step) {
       float v[VEC];
-      load_vec<TX, VEC>(x + m * ld + cgi * VEC, v);
+      load_vec<TX, VEC>(xp + m * ld, v);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const double d = (double)v[j];
@@ -108,7 +172,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_pm_kernel(const TX* __res
       }
     }
   }
-  block_reduce_pm<VEC, double>(a, b, C, g, partials + (size_t)blockIdx.x * 2 * C);
+  block_reduce_pm<VEC, double>(a, b, t, partials + (size_t)blockIdx.x * 2 * C, C);
 }
 
 // g = dz * mask * mask_scale * [x*scale+shift > 0]
@@ -130,27 +194,43 @@ __device__ __forceinline__ void grad_through_act(float (&gz)[VEC], const float (
 
 template <typename TG, typename TX, int VEC>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_pm_kernel(
-    const TG* __restrict__ dz, int dz_ld, const TX* __restrict__ x, int x_ld, long long M, int C, PmGeom g,
+    const TG* __restrict__ dz, int dz_ld, const TX* __restrict__ x, int x_ld, long long M, int C,
     const float* __restrict__ mean, const float* __restrict__ inv_std, const float* __restrict__ scale,
     const float* __restrict__ shift, int relu, const uint8_t* __restrict__ mask, float mask_scale,
     double* __restrict__ partials) {
-  const int cgi = threadIdx.x % g.cg, pr = threadIdx.x / g.cg;
+  const PmThread t = pm_thread<VEC>(C, M);
   float a[VEC], b[VEC], mu[VEC], is[VEC], sc[VEC], sh[VEC];
+  const int c0 = t.c_base + (t.active ? t.cgi * VEC : 0);
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
     a[j] = b[j] = 0.f;
-    const int c = (cgi * VEC + j) % C;
-    mu[j] = mean[c]; is[j] = inv_std[c]; sc[j] = scale[c]; sh[j] = shift[c];
+    mu[j] = mean[c0 + j]; is[j] = inv_std[c0 + j]; sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j];
   }
-  const long long per = (M + gridDim.x - 1) / gridDim.x;
-  const long long m0 = (long long)blockIdx.x * per;
-  const long long m1 = m0 + per < M ? m0 + per : M;
-  if (pr < g.rpb) {
-    for (long long m = m0 + pr; m < m1; m += g.rpb) {
+  if (t.active) {
+    const long long step = t.rpb;
+    long long m = t.m0 + t.pr;
+    for (; m + step < t.m1; m += 2 * step) {
+      float gz[2][VEC], xv[2][VEC];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        load_vec<TG, VEC>(dz + (m + k * step) * dz_ld + c0, gz[k]);
+        load_vec<TX, VEC>(x + (m + k * step) * x_ld + c0, xv[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        grad_through_act<VEC>(gz[k], xv[k], sc, sh, relu, mask ? mask + (m + k * step) * C + c0 : nullptr, mask_scale);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          a[j] += gz[k][j];
+          b[j] = fmaf(gz[k][j], (xv[k][j] - mu[j]) * is[j], b[j]);
+        }
+      }
+    }
+    for (; m < t.m1; m += step) {
       float gz[VEC], xv[VEC];
-      load_vec<TG, VEC>(dz + m * dz_ld + cgi * VEC, gz);
-      load_vec<TX, VEC>(x + m * x_ld + cgi * VEC, xv);
-      grad_through_act<VEC>(gz, xv, sc, sh, relu, mask ? mask + m * C + cgi * VEC : nullptr, mask_scale);
+      load_vec<TG, VEC>(dz + m * dz_ld + c0, gz);
+      load_vec<TX, VEC>(x + m * x_ld + c0, xv);
+      grad_through_act<VEC>(gz, xv, sc, sh, relu, mask ? mask + m * C + c0 : nullptr, mask_scale);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         a[j] += gz[j];
@@ -158,26 +238,30 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_pm_kernel(
       }
     }
   }
-  block_reduce_pm<VEC, float>(a, b, C, g, partials + (size_t)blockIdx.x * 2 * C);
+  block_reduce_pm<VEC, float>(a, b, t, partials + (size_t)blockIdx.x * 2 * C, C);
 }
 
 template <typename TX, typename TY, int VEC>
 __global__ __launch_bounds__(BN_THREADS) void bn_apply_pm_kernel(const TX* __restrict__ x, int x_ld, TY* __restrict__ y,
-                                                                  int y_ld, long long M, int C, int cg,
+                                                                  int y_ld, long long M, int C,
                                                                   const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, int relu,
                                                                   const uint8_t* __restrict__ mask, float mask_scale) {
-  const long long total = M * cg;
-  for (long long i = (long long)blockIdx.x * BN_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * BN_THREADS) {
-    const long long m = i / cg;
-    const int c0 = (int)(i - m * cg) * VEC;
+  const PmThread t = pm_thread<VEC>(C, M);
+  if (!t.active) return;
+  const int c0 = t.c_base + t.cgi * VEC;
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
+#pragma unroll 4
+  for (long long m = t.m0 + t.pr; m < t.m1; m += t.rpb) {
     float v[VEC], o[VEC];
     load_vec<TX, VEC>(x + m * x_ld + c0, v);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      float t = fmaf(v[j], scale[c0 + j], shift[c0 + j]);
-      if (relu) t = t > 0.f ? t : 0.f;
-      o[j] = t;
+      float r = fmaf(v[j], sc[j], sh[j]);
+      if (relu) r = r > 0.f ? r : 0.f;
+      o[j] = r;
     }
     if (mask) {
       float mk[VEC];
@@ -192,30 +276,29 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_pm_kernel(const TX* __res
 template <typename TG, typename TX, int VEC>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_pm_kernel(
     const TG* __restrict__ dz, int dz_ld, const TX* __restrict__ x, int x_ld, TG* __restrict__ dx, int dx_ld,
-    long long M, int C, int cg, const float* __restrict__ mean, const float* __restrict__ inv_std,
+    long long M, int C, const float* __restrict__ mean, const float* __restrict__ inv_std,
     const float* __restrict__ scale, const float* __restrict__ shift, int relu, const uint8_t* __restrict__ mask,
     float mask_scale, const double* __restrict__ gsums, int eval) {
-  const long long total = M * cg;
+  const PmThread t = pm_thread<VEC>(C, M);
+  if (!t.active) return;
+  const int c0 = t.c_base + t.cgi * VEC;
   const float inv_count = eval ? 0.f : (float)(1.0 / gsums[2 * C]);
-  for (long long i = (long long)blockIdx.x * BN_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * BN_THREADS) {
-    const long long m = i / cg;
-    const int c0 = (int)(i - m * cg) * VEC;
-    float gz[VEC], xv[VEC], o[VEC], sc[VEC], sh[VEC];
+  float sc[VEC], sh[VEC], mu[VEC], is[VEC], k1[VEC], k2[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
+  for (int j = 0; j < VEC; ++j) {
+    sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; mu[j] = mean[c0 + j]; is[j] = inv_std[c0 + j];
+    k1[j] = eval ? 0.f : (float)gsums[c0 + j] * inv_count;
+    k2[j] = eval ? 0.f : (float)gsums[C + c0 + j] * inv_count;
+  }
+#pragma unroll 2
+  for (long long m = t.m0 + t.pr; m < t.m1; m += t.rpb) {
+    float gz[VEC], xv[VEC], o[VEC];
     load_vec<TG, VEC>(dz + m * dz_ld + c0, gz);
     load_vec<TX, VEC>(x + m * x_ld + c0, xv);
     grad_through_act<VEC>(gz, xv, sc, sh, relu, mask ? mask + m * C + c0 : nullptr, mask_scale);
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      const int c = c0 + j;
-      if (eval) {
-        o[j] = sc[j] * gz[j];
-      } else {
-        const float xh = (xv[j] - mean[c]) * inv_std[c];
-        o[j] = sc[j] * (gz[j] - (float)gsums[c] * inv_count - xh * ((float)gsums[C + c] * inv_count));
-      }
-    }
+    for (int j = 0; j < VEC; ++j)
+      o[j] = eval ? sc[j] * gz[j] : sc[j] * (gz[j] - k1[j] - (xv[j] - mu[j]) * is[j] * k2[j]);
     store_vec<TG, VEC>(dx + m * dx_ld + c0, o);
   }
 }
@@ -404,19 +487,47 @@ __global__ void bn_coeffs_eval_kernel(const float* __restrict__ running_mean, co
 
 static bool aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 
-static PmGeom pm_geom(int C, int vec) {
-  PmGeom g;
-  g.cg = C / vec;
-  g.rpb = BN_THREADS / g.cg;
-  return g;
-}
-
-static int pm_rows(long long M) {
-  long long r = (M + 255) / 256;
+// partial rows (= pixel ranges = grid.x) of the pixel-major statistics kernels
+static int pm_rows(long long M, int C) {
+  long long cap = 524288 / (C > 0 ? C : 1);
+  if (cap < 64) cap = 64;
+  if (cap > BN_MAX_ROWS_PM) cap = BN_MAX_ROWS_PM;
+  long long r = (M + 63) / 64;
   if (r < 1) r = 1;
-  if (r > BN_MAX_ROWS_PM) r = BN_MAX_ROWS_PM;
+  if (r > cap) r = cap;
   return (int)r;
 }
+
+// widest channel vector every operand allows: 8 or 4 elements need C and the leading dimensions to be
+// multiples of it and 16-byte aligned base pointers (8-byte for 4 bf16)
+static int pm_vec(int C, std::initializer_list<int> lds, std::initializer_list<std::pair<const void*, int>> ptrs,
+                  const uint8_t* mask) {
+  for (int v : {8, 4}) {
+    bool ok = C % v == 0 && (!mask || aligned(mask, v));
+    for (int ld : lds) ok = ok && ld % v == 0;
+    for (auto& p : ptrs) ok = ok && aligned(p.first, p.second == SEGK_BF16 ? 2 * v : 16);
+    if (ok) return v;
+  }
+  return 1;
+}
+
+// grid of the pixel-major elementwise kernels: about eight pixels per thread
+static dim3 pm_apply_grid(long long M, int C, int vec) {
+  const int slab = BN_THREADS * vec;
+  const int cg = (C < slab ? C : slab) / vec;
+  const int rpb = BN_THREADS / cg;
+  long long gx = (M + rpb * 8 - 1) / (rpb * 8);
+  if (gx < 1) gx = 1;
+  if (gx > 4096) gx = 4096;
+  return dim3((unsigned)gx, (unsigned)ceil_div(C, slab));
+}
+
+#define SEGK_DISPATCH_VEC(vec, V, ...)             \
+  do {                                             \
+    if ((vec) == 8) { constexpr int V = 8; __VA_ARGS__; }      \
+    else if ((vec) == 4) { constexpr int V = 4; __VA_ARGS__; } \
+    else { constexpr int V = 1; __VA_ARGS__; }                 \
+  } while (0)
 
 static int nchw_rows(int N, int HW) {
   long long r = ((long long)N * HW + 8191) / 8192;
@@ -424,13 +535,6 @@ static int nchw_rows(int N, int HW) {
   if (r > BN_MAX_ROWS_NCHW) r = BN_MAX_ROWS_NCHW;
   if (r > HW) r = HW;
   return (int)r;
-}
-
-static int apply_grid(long long work_items) {
-  long long b = (work_items + BN_THREADS - 1) / BN_THREADS;
-  if (b < 1) b = 1;
-  if (b > 8192) b = 8192;
-  return (int)b;
 }
 
 // slices of the pixel range per (n, c) plane for the NCHW apply kernels
@@ -450,13 +554,11 @@ using namespace segk;
 #define BN_COMMON_CHECK(name)                                                                                       \
   SEGK_REQUIRE(N > 0 && C > 0 && HW > 0, name ": bad shape N=%d C=%d HW=%d", N, C, HW);                             \
   SEGK_REQUIRE(layout == SEGK_PM || layout == SEGK_NCHW, name ": bad layout %d", layout);                           \
-  SEGK_REQUIRE(layout == SEGK_NCHW || C <= 1024, name ": pixel-major layout supports C <= 1024 (got %d)", C);        \
   SEGK_REQUIRE(layout == SEGK_PM || (long long)N * C < 2147483647LL, name ": too many planes")
 
 extern "C" int segk_bn_stat_rows(int layout, int N, int C, int HW) {
-  (void)C;
-  if (N <= 0 || HW <= 0) return SEGK_INVALID_ARG;
-  return layout == SEGK_PM ? pm_rows((long long)N * HW) : nchw_rows(N, HW);
+  if (N <= 0 || HW <= 0 || C <= 0) return SEGK_INVALID_ARG;
+  return layout == SEGK_PM ? pm_rows((long long)N * HW, C) : nchw_rows(N, HW);
 }
 
 extern "C" int segk_bn_stats(const void* x, int dtype, int layout, int N, int C, int HW, int ld, double* partials,
@@ -467,15 +569,10 @@ extern "C" int segk_bn_stats(const void* x, int dtype, int layout, int N, int C,
   if (layout == SEGK_PM) {
     SEGK_REQUIRE(ld >= C, "bn_stats: ld %d < C %d", ld, C);
     const long long M = (long long)N * HW;
-    const int rows = pm_rows(M);
-    const bool v4 = (C % 4 == 0) && (ld % 4 == 0) && aligned(x, dtype == SEGK_BF16 ? 8 : 16) && C / 4 <= BN_THREADS;
-    SEGK_REQUIRE(v4 || C <= BN_THREADS, "bn_stats: C=%d needs 4-element alignment in pixel-major layout", C);
-    SEGK_DISPATCH_DTYPE(dtype, T, {
-      if (v4)
-        bn_stats_pm_kernel<T, 4><<<rows, BN_THREADS, 0, st>>>((const T*)x, ld, M, C, pm_geom(C, 4), partials);
-      else
-        bn_stats_pm_kernel<T, 1><<<rows, BN_THREADS, 0, st>>>((const T*)x, ld, M, C, pm_geom(C, 1), partials);
-    });
+    const int rows = pm_rows(M, C);
+    const int vec = pm_vec(C, {ld}, {{x, dtype}}, nullptr);
+    SEGK_DISPATCH_DTYPE(dtype, T, SEGK_DISPATCH_VEC(vec, V, (bn_stats_pm_kernel<T, V><<<dim3(rows, ceil_div(C, BN_THREADS * V)), BN_THREADS, 0, st>>>(
+        (const T*)x, ld, M, C, partials))));
   } else {
     SEGK_REQUIRE(C <= 2147483647, "bn_stats: C too large");
     dim3 grid(C, nchw_rows(N, HW));
@@ -525,18 +622,11 @@ extern "C" int segk_bn_apply(const void* x, int x_dtype, int x_ld, void* y, int 
   if (layout == SEGK_PM) {
     SEGK_REQUIRE(x_ld >= C && y_ld >= C, "bn_apply: ld (%d,%d) < C %d", x_ld, y_ld, C);
     const long long M = (long long)N * HW;
-    const bool v4 = (C % 4 == 0) && (x_ld % 4 == 0) && (y_ld % 4 == 0) && aligned(x, x_dtype == SEGK_BF16 ? 8 : 16) &&
-                    aligned(y, y_dtype == SEGK_BF16 ? 8 : 16) && (!mask || aligned(mask, 4));
-    const int vec = v4 ? 4 : 1;
-    const int cg = C / vec;
-    const int grid = apply_grid(M * cg);
-#define LAUNCH_APPLY(TX, TY)                                                                                     \
-  if (v4)                                                                                                        \
-    bn_apply_pm_kernel<TX, TY, 4><<<grid, BN_THREADS, 0, st>>>((const TX*)x, x_ld, (TY*)y, y_ld, M, C, cg, scale, \
-                                                               shift, relu, mask, mask_scale);                   \
-  else                                                                                                           \
-    bn_apply_pm_kernel<TX, TY, 1><<<grid, BN_THREADS, 0, st>>>((const TX*)x, x_ld, (TY*)y, y_ld, M, C, cg, scale, \
-                                                               shift, relu, mask, mask_scale)
+    const int vec = pm_vec(C, {x_ld, y_ld}, {{x, x_dtype}, {y, y_dtype}}, mask);
+    const dim3 grid = pm_apply_grid(M, C, vec);
+#define LAUNCH_APPLY(TX, TY)                                                                                       \
+  SEGK_DISPATCH_VEC(vec, V, (bn_apply_pm_kernel<TX, TY, V><<<grid, BN_THREADS, 0, st>>>(                           \
+                                (const TX*)x, x_ld, (TY*)y, y_ld, M, C, scale, shift, relu, mask, mask_scale)))
     if (x_dtype == SEGK_BF16 && y_dtype == SEGK_BF16) { LAUNCH_APPLY(bf16_t, bf16_t); }
     else if (x_dtype == SEGK_BF16) { LAUNCH_APPLY(bf16_t, float); }
     else if (y_dtype == SEGK_BF16) { LAUNCH_APPLY(float, bf16_t); }
@@ -568,19 +658,11 @@ extern "C" int segk_bn_bwd_stats(const void* dz, int dz_dtype, int dz_ld, const 
   if (layout == SEGK_PM) {
     SEGK_REQUIRE(x_ld >= C && dz_ld >= C, "bn_bwd_stats: ld (%d,%d) < C %d", dz_ld, x_ld, C);
     const long long M = (long long)N * HW;
-    const int rows = pm_rows(M);
-    const bool v4 = (C % 4 == 0) && (x_ld % 4 == 0) && (dz_ld % 4 == 0) && aligned(x, x_dtype == SEGK_BF16 ? 8 : 16) &&
-                    aligned(dz, dz_dtype == SEGK_BF16 ? 8 : 16) && (!mask || aligned(mask, 4)) && C / 4 <= BN_THREADS;
-    SEGK_REQUIRE(v4 || C <= BN_THREADS, "bn_bwd_stats: C=%d needs 4-element alignment in pixel-major layout", C);
+    const int rows = pm_rows(M, C);
+    const int vec = pm_vec(C, {x_ld, dz_ld}, {{x, x_dtype}, {dz, dz_dtype}}, mask);
 #define LAUNCH_BS(TG, TX)                                                                                           \
-  if (v4)                                                                                                           \
-    bn_bwd_stats_pm_kernel<TG, TX, 4><<<rows, BN_THREADS, 0, st>>>((const TG*)dz, dz_ld, (const TX*)x, x_ld, M, C,   \
-                                                                   pm_geom(C, 4), mean, inv_std, scale, shift, relu, \
-                                                                   mask, mask_scale, partials);                     \
-  else                                                                                                              \
-    bn_bwd_stats_pm_kernel<TG, TX, 1><<<rows, BN_THREADS, 0, st>>>((const TG*)dz, dz_ld, (const TX*)x, x_ld, M, C,   \
-                                                                   pm_geom(C, 1), mean, inv_std, scale, shift, relu, \
-                                                                   mask, mask_scale, partials)
+  SEGK_DISPATCH_VEC(vec, V, (bn_bwd_stats_pm_kernel<TG, TX, V><<<dim3(rows, ceil_div(C, BN_THREADS * V)), BN_THREADS, 0, st>>>( \
+      (const TG*)dz, dz_ld, (const TX*)x, x_ld, M, C, mean, inv_std, scale, shift, relu, mask, mask_scale, partials)))
     if (dz_dtype == SEGK_BF16 && x_dtype == SEGK_BF16) { LAUNCH_BS(bf16_t, bf16_t); }
     else if (dz_dtype == SEGK_BF16) { LAUNCH_BS(bf16_t, float); }
     else if (x_dtype == SEGK_BF16) { LAUNCH_BS(float, bf16_t); }
@@ -615,22 +697,12 @@ extern "C" int segk_bn_bwd_apply(const void* dz, int dz_dtype, int dz_ld, const 
   if (layout == SEGK_PM) {
     SEGK_REQUIRE(x_ld >= C && dz_ld >= C && dx_ld >= C, "bn_bwd_apply: ld (%d,%d,%d) < C %d", dz_ld, x_ld, dx_ld, C);
     const long long M = (long long)N * HW;
-    const size_t ga = dz_dtype == SEGK_BF16 ? 8 : 16;
-    const bool v4 = (C % 4 == 0) && (x_ld % 4 == 0) && (dz_ld % 4 == 0) && (dx_ld % 4 == 0) &&
-                    aligned(x, x_dtype == SEGK_BF16 ? 8 : 16) && aligned(dz, ga) && aligned(dx, ga) &&
-                    (!mask || aligned(mask, 4));
-    const int vec = v4 ? 4 : 1;
-    const int cg = C / vec;
-    const int grid = apply_grid(M * cg);
+    const int vec = pm_vec(C, {x_ld, dz_ld, dx_ld}, {{x, x_dtype}, {dz, dz_dtype}, {dx, dx_dtype}}, mask);
+    const dim3 grid = pm_apply_grid(M, C, vec);
 #define LAUNCH_BA(TG, TX)                                                                                            \
-  if (v4)                                                                                                            \
-    bn_bwd_apply_pm_kernel<TG, TX, 4><<<grid, BN_THREADS, 0, st>>>((const TG*)dz, dz_ld, (const TX*)x, x_ld, (TG*)dx, \
-                                                                   dx_ld, M, C, cg, mean, inv_std, scale, shift, relu, \
-                                                                   mask, mask_scale, gsums, eval);                   \
-  else                                                                                                               \
-    bn_bwd_apply_pm_kernel<TG, TX, 1><<<grid, BN_THREADS, 0, st>>>((const TG*)dz, dz_ld, (const TX*)x, x_ld, (TG*)dx, \
-                                                                   dx_ld, M, C, cg, mean, inv_std, scale, shift, relu, \
-                                                                   mask, mask_scale, gsums, eval)
+  SEGK_DISPATCH_VEC(vec, V, (bn_bwd_apply_pm_kernel<TG, TX, V><<<grid, BN_THREADS, 0, st>>>(                         \
+                                (const TG*)dz, dz_ld, (const TX*)x, x_ld, (TG*)dx, dx_ld, M, C, mean, inv_std, scale, \
+                                shift, relu, mask, mask_scale, gsums, eval)))
     if (dz_dtype == SEGK_BF16 && x_dtype == SEGK_BF16) { LAUNCH_BA(bf16_t, bf16_t); }
     else if (dz_dtype == SEGK_BF16) { LAUNCH_BA(bf16_t, float); }
     else if (x_dtype == SEGK_BF16) { LAUNCH_BA(float, bf16_t); }

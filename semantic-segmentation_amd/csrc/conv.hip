@@ -15,6 +15,8 @@
 //   bf16 fragments are read with the transposing ds_read_b64_tr_b16 and fp32 fragments with ds_read_b32.
 //   The pixel range is split over workgroups; each split writes its own fp32 slab (summed later in fixed
 //   order, so results are reproducible: no float atomics).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace segk {
@@ -83,13 +85,31 @@ __device__ __forceinline__ void store_out4<bf16_t>(char* p, const float (&v)[4])
   *reinterpret_cast<u32x2*>(p) = t;
 }
 
-template <typename T, int BKB, typename TO>
-__global__ __launch_bounds__(CONV_THREADS, 2) void conv_fwd_kernel(const ConvDev p) {
+// Tile geometry: a workgroup owns BCO output channels x BPX pixels with WCO x WPX wavefronts; each wavefront
+// owns (BCO/WCO) x (BPX/WPX) = MI x MJ MFMA 16x16 tiles.
+//   Small: 128 x 128, 2 x 2 waves (64 x 64 per wave), 2 workgroups per CU - problems with few tiles.
+//   Big:   256 x 256, 4 x 2 waves (64 co x 128 px per wave), 1 workgroup per CU - twice the MFMA work per byte
+//          staged through LDS and four times the work per barrier (hides the global-load latency of the
+//          one-step-ahead prefetch).
+template <int BCO_, int BPX_, int WCO_, int WPX_>
+struct TileCfg {
+  static constexpr int BCO = BCO_, BPX = BPX_, WCO = WCO_, WPX = WPX_;
+  static constexpr int THREADS = 64 * WCO_ * WPX_;
+  static constexpr int MI = BCO_ / WCO_ / 16, MJ = BPX_ / WPX_ / 16;
+};
+typedef TileCfg<128, 128, 2, 2> TileSmall;
+typedef TileCfg<256, 256, 4, 2> TileBig;
+
+template <typename T, int BKB, typename TO, typename G, int ABL = 0>
+__global__ __launch_bounds__(G::THREADS, (G::THREADS == 256 && G::BCO == 256) ? 1 : 2) void conv_fwd_kernel(const ConvDev p) {
+  constexpr int NT = G::THREADS;
   constexpr int CH = BKB / 16;               // 16-byte chunks per tile row
-  constexpr int RPP = CONV_THREADS / CH;     // rows loaded per pass
-  constexpr int NP = TILE / RPP;             // passes per operand tile
-  constexpr int TILE_B = TILE * BKB;
+  constexpr int RPP = NT / CH;               // rows loaded per pass
+  constexpr int NPA = G::BCO / RPP;          // passes for the weight tile
+  constexpr int NPB = G::BPX / RPP;          // passes for the activation tile
+  constexpr int TA_B = G::BCO * BKB, TB_B = G::BPX * BKB, STAGE_B = TA_B + TB_B;
   constexpr int KS = BKB / 64;               // MFMA k-steps per tile (one 16-byte chunk per lane per step)
+  constexpr int MI = G::MI, MJ = G::MJ;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int taps_l[SEGK_MAX_SEG * 9];
   __shared__ int ntaps_l[SEGK_MAX_SEG];
@@ -97,22 +117,24 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_fwd_kernel(const ConvDev
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;   // wave row (channels) / column (pixels) in the 2x2 grid
+  const int wr = wave / G::WPX, wc = wave % G::WPX;   // wave row (channels) / column (pixels)
   const int nt = blockIdx.x % p.n_tiles;
   const long long mt = blockIdx.x / p.n_tiles;
-  const int co0 = nt * TILE;
-  const long long m0 = mt * TILE;
+  const int co0 = nt * G::BCO;
+  const long long m0 = mt * G::BPX;
 
   const int lc = tid % CH, lr = tid / CH;
-  int wrow[NP], ry[NP], rx[NP];
-  long long rm[NP];
-  bool rvalid[NP];
+  int wrow[NPA], ry[NPB], rx[NPB];
+  long long rm[NPB];
+  bool rvalid[NPB];
 #pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const int row = lr + i * RPP;
-    int co = co0 + row;
+  for (int i = 0; i < NPA; ++i) {
+    const int co = co0 + lr + i * RPP;
     wrow[i] = co < p.Cout ? co : p.Cout - 1;
-    const long long m = m0 + row;
+  }
+#pragma unroll
+  for (int i = 0; i < NPB; ++i) {
+    const long long m = m0 + lr + i * RPP;
     rvalid[i] = m < p.M;
     const long long mm = rvalid[i] ? m : 0;
     rm[i] = mm;
@@ -132,7 +154,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_fwd_kernel(const ConvDev
         const int dy = (tap / R - (R >> 1)) * dil, dx = (tap % R - (R >> 1)) * dil;
         bool any = false;
 #pragma unroll
-        for (int i = 0; i < NP; ++i)
+        for (int i = 0; i < NPB; ++i)
           any |= rvalid[i] && (unsigned)(ry[i] + dy) < (unsigned)p.H && (unsigned)(rx[i] + dx) < (unsigned)p.W;
         if (any) mine |= 1ull << (sg * 9 + tap);
       }
@@ -156,71 +178,89 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_fwd_kernel(const ConvDev
   int total = 0;
   for (int sg = 0; sg < p.nseg; ++sg) total += ntaps_l[sg] * (p.seg[sg].ck_b / BKB);
 
-  f32x4 acc[4][4];
+  f32x4 acc[MI][MJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (total > 0) {
     // ---- K-loop state ---------------------------------------------------------------------
+    // Order: segment -> 64-channel chunk -> tap (the nine shifted windows of one channel chunk follow each
+    // other, so their overlapping pixel rows stay in L2).  Addresses are a wave-uniform 64-bit base (tile
+    // origin + tap shift + chunk) plus a per-thread 32-bit offset, which keeps address registers few.
     int sg = 0;
     while (ntaps_l[sg] == 0) ++sg;
     int ti = 0, kc = 0, nkc = p.seg[sg].ck_b / BKB;
-    const char* aptr[NP];
-    const char* bptr[NP];
-    bool bok[NP];
+    unsigned aoff[NPA], boff[NPB];
+    bool bok[NPB];
+    const char* abase = nullptr;
+    const char* bbase = nullptr;
+    auto setup_seg = [&]() {
+      const SegDev& s = p.seg[sg];
+#pragma unroll
+      for (int i = 0; i < NPA; ++i) aoff[i] = (unsigned)(wrow[i] - co0) * (unsigned)s.ck_b + lc * 16;
+#pragma unroll
+      for (int i = 0; i < NPB; ++i) boff[i] = (unsigned)(rm[i] >= m0 ? rm[i] - m0 : 0) * (unsigned)s.in_ld_b + lc * 16;
+    };
     auto setup_tap = [&]() {
       const SegDev& s = p.seg[sg];
       const int tap = taps_l[sg * 9 + ti];
       const int R = s.R;
       const int dy = (tap / R - (R >> 1)) * s.dil, dx = (tap % R - (R >> 1)) * s.dil;
+      abase = s.w + (long long)tap * s.w_tap_b + (long long)co0 * s.ck_b + (long long)kc * BKB;
+      bbase = s.in + (m0 + (long long)dy * p.W + dx) * s.in_ld_b + (long long)kc * BKB;
 #pragma unroll
-      for (int i = 0; i < NP; ++i) {
-        aptr[i] = s.w + (long long)tap * s.w_tap_b + (long long)wrow[i] * s.ck_b + lc * 16;
+      for (int i = 0; i < NPB; ++i)
         bok[i] = rvalid[i] && (unsigned)(ry[i] + dy) < (unsigned)p.H && (unsigned)(rx[i] + dx) < (unsigned)p.W;
-        bptr[i] = s.in + (rm[i] + (long long)dy * p.W + dx) * s.in_ld_b + lc * 16;
-      }
     };
     auto advance = [&]() {
-      if (++kc < nkc) {
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-          aptr[i] += BKB;
-          bptr[i] += BKB;
-        }
-        return;
-      }
-      kc = 0;
       if (++ti >= ntaps_l[sg]) {
         ti = 0;
-        ++sg;
-        while (ntaps_l[sg] == 0) ++sg;
-        nkc = p.seg[sg].ck_b / BKB;
+        if (++kc >= nkc) {
+          kc = 0;
+          ++sg;
+          while (ntaps_l[sg] == 0) ++sg;
+          nkc = p.seg[sg].ck_b / BKB;
+          setup_seg();
+        }
       }
       setup_tap();
     };
-    u32x4 ra[NP], rb[NP];
+    u32x4 ra[NPA], rb[NPB];
     auto load_tile = [&]() {
+      if (ABL == 1 || ABL == 3) {  // ablation: no global loads (results are garbage, timing only)
 #pragma unroll
-      for (int i = 0; i < NP; ++i) ra[i] = *reinterpret_cast<const u32x4*>(aptr[i]);
+        for (int i = 0; i < NPA; ++i) asm volatile("" : "+v"(ra[i]));
 #pragma unroll
-      for (int i = 0; i < NP; ++i) {
+        for (int i = 0; i < NPB; ++i) asm volatile("" : "+v"(rb[i]));
+        return;
+      }
+#pragma unroll
+      for (int i = 0; i < NPA; ++i) ra[i] = *reinterpret_cast<const u32x4*>(abase + aoff[i]);
+#pragma unroll
+      for (int i = 0; i < NPB; ++i) {
         u32x4 z = {0u, 0u, 0u, 0u};
-        rb[i] = bok[i] ? *reinterpret_cast<const u32x4*>(bptr[i]) : z;
+        rb[i] = bok[i] ? *reinterpret_cast<const u32x4*>(bbase + boff[i]) : z;
       }
     };
     auto store_tile = [&](int stage) {
-      char* sa = smem + stage * 2 * TILE_B;
-      char* sb = sa + TILE_B;
+      if (ABL == 2 || ABL == 3) {  // ablation: no LDS writes
 #pragma unroll
-      for (int i = 0; i < NP; ++i) {
-        const int off = tile_off<BKB>(lr + i * RPP, lc);
-        *reinterpret_cast<u32x4*>(sa + off) = ra[i];
-        *reinterpret_cast<u32x4*>(sb + off) = rb[i];
+        for (int i = 0; i < NPA; ++i) asm volatile("" ::"v"(ra[i]));
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) asm volatile("" ::"v"(rb[i]));
+        return;
       }
+      char* sa = smem + stage * STAGE_B;
+      char* sb = sa + TA_B;
+#pragma unroll
+      for (int i = 0; i < NPA; ++i) *reinterpret_cast<u32x4*>(sa + tile_off<BKB>(lr + i * RPP, lc)) = ra[i];
+#pragma unroll
+      for (int i = 0; i < NPB; ++i) *reinterpret_cast<u32x4*>(sb + tile_off<BKB>(lr + i * RPP, lc)) = rb[i];
     };
 
+    setup_seg();
     setup_tap();
     load_tile();
     store_tile(0);
@@ -233,41 +273,40 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_fwd_kernel(const ConvDev
         advance();
         load_tile();
       }
-      const char* sa = smem + cur * 2 * TILE_B;
-      const char* sb = sa + TILE_B;
+      const char* sa = smem + cur * STAGE_B;
+      const char* sb = sa + TA_B;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        u32x4 fa[4], fb[4];
+        u32x4 fb[MJ];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          fa[i] = *reinterpret_cast<const u32x4*>(sa + tile_off<BKB>(wr * 64 + i * 16 + frow, ks * 4 + fg));
+        for (int j = 0; j < MJ; ++j)
+          fb[j] = *reinterpret_cast<const u32x4*>(sb + tile_off<BKB>(wc * (MJ * 16) + j * 16 + frow, ks * 4 + fg));
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          fb[j] = *reinterpret_cast<const u32x4*>(sb + tile_off<BKB>(wc * 64 + j * 16 + frow, ks * 4 + fg));
+        for (int i = 0; i < MI; ++i) {
+          const u32x4 fa = *reinterpret_cast<const u32x4*>(sa + tile_off<BKB>(wr * (MI * 16) + i * 16 + frow, ks * 4 + fg));
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+          for (int j = 0; j < MJ; ++j) Mma<T>::run(fa, fb[j], acc[i][j]);
+        }
       }
       if (more) store_tile(cur ^ 1);
       __syncthreads();
     }
   }
 
-  // ---- epilogue: acc[i][j][r] = out[pixel = wc*64 + j*16 + (lane&15)][co = wr*64 + i*16 + (lane>>4)*4 + r]
+  // ---- epilogue: acc[i][j][r] = out[pixel = wc*MJ*16 + j*16 + (lane&15)][co = wr*MI*16 + i*16 + (lane>>4)*4 + r]
   const int fq = lane >> 4, fr = lane & 15;
   if (p.stat) {
     // fp64 sums: the squares of the fp32 accumulators are exact in fp64
-    double* red = reinterpret_cast<double*>(smem);  // [2 pixel halves][2][128]
+    double* red = reinterpret_cast<double*>(smem);  // [WPX pixel parts][2][BCO]
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
       double s[4], q[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         s[r] = 0.0;
         q[r] = 0.0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < MJ; ++j) {
           const double v = (double)acc[i][j][r];
           s[r] += v;
           q[r] = fma(v, v, q[r]);
@@ -281,30 +320,35 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_fwd_kernel(const ConvDev
       if (fr == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int cl = wr * 64 + i * 16 + fq * 4 + r;
-          red[(wc * 2 + 0) * TILE + cl] = s[r];
-          red[(wc * 2 + 1) * TILE + cl] = q[r];
+          const int cl = wr * (MI * 16) + i * 16 + fq * 4 + r;
+          red[(wc * 2 + 0) * G::BCO + cl] = s[r];
+          red[(wc * 2 + 1) * G::BCO + cl] = q[r];
         }
       }
     }
     __syncthreads();
-    if (tid < 2 * TILE) {
-      const int which = tid / TILE, cl = tid % TILE;
+    for (int t = tid; t < 2 * G::BCO; t += NT) {
+      const int which = t / G::BCO, cl = t % G::BCO;
       const int co = co0 + cl;
-      if (co < p.Cout) p.stat[((size_t)mt * 2 + which) * p.Cout + co] = red[which * TILE + cl] + red[(2 + which) * TILE + cl];
+      if (co < p.Cout) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < G::WPX; ++w) v += red[(w * 2 + which) * G::BCO + cl];
+        p.stat[((size_t)mt * 2 + which) * p.Cout + co] = v;
+      }
     }
   }
 
   const int cpad = (p.Cout + 3) & ~3;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const long long m = m0 + wc * 64 + j * 16 + fr;
+  for (int j = 0; j < MJ; ++j) {
+    const long long m = m0 + wc * (MJ * 16) + j * 16 + fr;
     if (m >= p.M) continue;
     const long long n = m / p.HW;
     char* orow = p.out + (size_t)m * p.out_ld * sizeof(TO);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = co0 + wr * 64 + i * 16 + fq * 4;
+    for (int i = 0; i < MI; ++i) {
+      const int c = co0 + wr * (MI * 16) + i * 16 + fq * 4;
       if (c >= cpad) continue;
       float v[4];
 #pragma unroll
@@ -535,17 +579,34 @@ static int set_lds(K kernel, int bytes, const char* name) {
   return SEGK_OK;
 }
 
-template <typename T, int BKB, typename TO>
-static int launch_fwd(const ConvDev& d, int blocks, hipStream_t st) {
-  const int lds = 4 * TILE * BKB;
+template <typename T, int BKB, typename TO, typename G, int ABL = 0>
+static int launch_fwd(ConvDev& d, hipStream_t st) {
+  const int lds = 2 * (G::BCO + G::BPX) * BKB;
   static bool configured = false;  // per instantiation
   if (!configured) {
-    int rc = set_lds(conv_fwd_kernel<T, BKB, TO>, lds, "conv_fwd");
+    int rc = set_lds(conv_fwd_kernel<T, BKB, TO, G, ABL>, lds, "conv_fwd");
     if (rc != SEGK_OK) return rc;
     configured = true;
   }
-  conv_fwd_kernel<T, BKB, TO><<<blocks, CONV_THREADS, lds, st>>>(d);
+  d.n_tiles = ceil_div(d.Cout, G::BCO);
+  const long long blocks = ((d.M + G::BPX - 1) / G::BPX) * d.n_tiles;
+  if (blocks >= 2147483647LL) {
+    set_error("conv: too many tiles");
+    return SEGK_INVALID_ARG;
+  }
+  conv_fwd_kernel<T, BKB, TO, G, ABL><<<(int)blocks, G::THREADS, lds, st>>>(d);
   return SEGK_OK;
+}
+
+// Rows of statistic partials = pixel tiles of the geometry chosen for this problem.
+static bool use_big_tile(const ConvDev& d, bool wide) {
+  // the big tile needs 128-byte K rows, full 256-channel tiles and enough tiles to fill 256 CUs twice
+  if (!wide || d.Cout % TileBig::BCO != 0) return false;
+  static const char* force = getenv("SEGK_CONV_TILE");  // experiments: "small" / "big"
+  if (force && force[0] == 's') return false;
+  if (force && (force[0] == 'b' || force[0] == 'h')) return true;
+  const long long tiles = ((d.M + TileBig::BPX - 1) / TileBig::BPX) * (d.Cout / TileBig::BCO);
+  return tiles >= 512;
 }
 
 }  // namespace segk
@@ -574,19 +635,12 @@ static int conv_check(const segk_conv_args* a) {
   return SEGK_OK;
 }
 
-extern "C" int segk_conv_stat_rows(const segk_conv_args* a) {
-  if (!a || a->N <= 0 || a->H <= 0 || a->W <= 0) return SEGK_INVALID_ARG;
-  return ceil_div((long long)a->N * a->H * a->W, TILE);
-}
-
-extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
-  int rc = conv_check(a);
-  if (rc != SEGK_OK) return rc;
-  ConvDev d;
+// Device-side description of the problem; returns whether every segment has 128-byte K rows.
+static bool fill_dev(const segk_conv_args* a, ConvDev& d) {
   d.H = a->H; d.W = a->W; d.HW = a->H * a->W;
   d.M = (long long)a->N * d.HW;
   d.Cout = a->Cout; d.nseg = a->nseg;
-  d.n_tiles = ceil_div(a->Cout, TILE);
+  d.n_tiles = 0;
   const int es = dtype_size(a->dtype);
   bool wide = true;
   for (int s = 0; s < SEGK_MAX_SEG; ++s) {
@@ -602,21 +656,45 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
   }
   d.out = (char*)a->out; d.out_ld = a->out_ld;
   d.bias = a->bias; d.img_bias = a->img_bias; d.stat = a->stat_partials;
-  const long long mtiles = (d.M + TILE - 1) / TILE;
-  const long long blocks = mtiles * d.n_tiles;
-  SEGK_REQUIRE(blocks < 2147483647LL, "conv: too many tiles");
+  return wide;
+}
+
+extern "C" int segk_conv_stat_rows(const segk_conv_args* a) {
+  if (!a || a->N <= 0 || a->H <= 0 || a->W <= 0 || a->nseg < 1 || a->nseg > SEGK_MAX_SEG || !valid_dtype(a->dtype))
+    return SEGK_INVALID_ARG;
+  ConvDev d;
+  const bool wide = fill_dev(a, d);
+  return ceil_div(d.M, use_big_tile(d, wide) ? TileBig::BPX : TileSmall::BPX);
+}
+
+extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
+  int rc = conv_check(a);
+  if (rc != SEGK_OK) return rc;
+  ConvDev d;
+  const bool wide = fill_dev(a, d);
+  const bool big = use_big_tile(d, wide);
   hipStream_t st = (hipStream_t)stream;
-  if (a->dtype == SEGK_BF16) {
-    if (a->out_dtype == SEGK_BF16)
-      rc = wide ? launch_fwd<bf16_t, 128, bf16_t>(d, (int)blocks, st) : launch_fwd<bf16_t, 64, bf16_t>(d, (int)blocks, st);
-    else
-      rc = wide ? launch_fwd<bf16_t, 128, float>(d, (int)blocks, st) : launch_fwd<bf16_t, 64, float>(d, (int)blocks, st);
-  } else {
-    if (a->out_dtype == SEGK_BF16)
-      rc = launch_fwd<float, 128, bf16_t>(d, (int)blocks, st);
-    else
-      rc = launch_fwd<float, 128, float>(d, (int)blocks, st);
+  static const char* abl = getenv("SEGK_CONV_ABL");
+  if (abl && big && a->dtype == SEGK_BF16 && a->out_dtype == SEGK_BF16) {
+    rc = abl[0] == '1' ? launch_fwd<bf16_t, 128, bf16_t, TileBig, 1>(d, st)
+       : abl[0] == '2' ? launch_fwd<bf16_t, 128, bf16_t, TileBig, 2>(d, st)
+                       : launch_fwd<bf16_t, 128, bf16_t, TileBig, 3>(d, st);
+    if (rc != SEGK_OK) return rc;
+    SEGK_CHECK_LAUNCH("conv_fwd");
+    return SEGK_OK;
   }
+#define SEGK_LAUNCH(T, TO)                                                          \
+  (big ? launch_fwd<T, 128, TO, TileBig>(d, st)                                     \
+       : (wide ? launch_fwd<T, 128, TO, TileSmall>(d, st) : launch_fwd<T, 64, TO, TileSmall>(d, st)))
+  if (a->dtype == SEGK_BF16) {
+    rc = a->out_dtype == SEGK_BF16 ? SEGK_LAUNCH(bf16_t, bf16_t) : SEGK_LAUNCH(bf16_t, float);
+  } else {
+    // fp32 rows of 32 channels are always 128 bytes
+    rc = a->out_dtype == SEGK_BF16
+             ? (big ? launch_fwd<float, 128, bf16_t, TileBig>(d, st) : launch_fwd<float, 128, bf16_t, TileSmall>(d, st))
+             : (big ? launch_fwd<float, 128, float, TileBig>(d, st) : launch_fwd<float, 128, float, TileSmall>(d, st));
+  }
+#undef SEGK_LAUNCH
   if (rc != SEGK_OK) return rc;
   SEGK_CHECK_LAUNCH("conv_fwd");
   return SEGK_OK;

@@ -229,10 +229,10 @@ __global__ __launch_bounds__(256) void upsample_bwd_nchw_kernel(const float* __r
 
 // Tiled form of the NCHW gradient for up-sampling ratios up to ~4.5x: a block owns a 16x16 tile of input
 // pixels of one image and walks up to 32 channels.  Per channel the output-gradient window that feeds the
-// tile (<= 72x72) is staged in LDS with coalesced row reads, every thread accumulates its <= 12x12 window
+// tile (<= 76x76) is staged in LDS with coalesced row reads, every thread accumulates its <= 12x12 window
 // with weights precomputed once per tile row/column, and the per-pixel channel vectors leave through LDS so
 // the pixel-major store is contiguous.  HBM traffic ~= 1.1x the gradient tensor, read once.
-constexpr int UB_TI = 16, UB_MAXR = 72, UB_MAXK = 12, UB_CCH = 32;
+constexpr int UB_TI = 16, UB_MAXR = 76, UB_MAXK = 12, UB_CCH = 32;
 
 template <typename TG>
 __global__ __launch_bounds__(256) void upsample_bwd_nchw_tiled_kernel(const float* __restrict__ dout, int C, int Ho,

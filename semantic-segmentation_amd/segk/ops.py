@@ -20,8 +20,20 @@ def _dt(t):
     raise TypeError("segk supports float32 and bfloat16 tensors, got %s" % (t.dtype,))
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream (the raw getter is ~20x cheaper than building a Stream object)."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _row_ptrs(coef):
+    """Pointers to the four rows (mean, inv_std, scale, shift) of a contiguous [4, C] float32 tensor."""
+    base, step = coef.data_ptr(), coef.shape[1] * 4
+    return [ctypes.c_void_p(base + i * step) for i in range(4)]
 
 
 def _ptr(t):
@@ -242,9 +254,9 @@ def bn_coeffs(sums, gamma, beta, eps, momentum, running_mean, running_var, legac
         raise ValueError("batch-norm sums are float64")
     coef = torch.empty((4, C), dtype=torch.float32, device=sums.device)
     _dev(sums, gamma, beta, running_mean, running_var)
+    r = _row_ptrs(coef)
     call("segk_bn_coeffs", _ptr(sums), _ptr(gamma), _ptr(beta), ctypes.c_float(eps), ctypes.c_float(momentum),
-         1 if legacy_clamp else 0, _ptr(running_mean), _ptr(running_var), _ptr(coef[0]), _ptr(coef[1]),
-         _ptr(coef[2]), _ptr(coef[3]), C, _stream())
+         1 if legacy_clamp else 0, _ptr(running_mean), _ptr(running_var), r[0], r[1], r[2], r[3], C, _stream())
     return coef
 
 
@@ -252,8 +264,9 @@ def bn_coeffs_eval(running_mean, running_var, gamma, beta, eps):
     C = running_mean.numel()
     _dev(running_mean, running_var, gamma, beta)
     coef = torch.empty((4, C), dtype=torch.float32, device=running_mean.device)
+    r = _row_ptrs(coef)
     call("segk_bn_coeffs_eval", _ptr(running_mean), _ptr(running_var), _ptr(gamma), _ptr(beta),
-         ctypes.c_float(eps), _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]), _ptr(coef[3]), C, _stream())
+         ctypes.c_float(eps), r[0], r[1], r[2], r[3], C, _stream())
     return coef
 
 
@@ -272,8 +285,9 @@ def bn_apply(x, y, coef, layout, relu, mask=None, mask_scale=1.0):
     if y.shape != x.shape:
         raise ValueError("bn_apply output shape %s != input shape %s" % (tuple(y.shape), tuple(x.shape)))
     _mask_check(mask, x)
-    call("segk_bn_apply", _ptr(x), _dt(x), x_ld, _ptr(y), _dt(y), y_ld, layout, N, C, HW, _ptr(coef[2]),
-         _ptr(coef[3]), 1 if relu else 0, _ptr(mask), ctypes.c_float(mask_scale), _stream())
+    r = _row_ptrs(coef)
+    call("segk_bn_apply", _ptr(x), _dt(x), x_ld, _ptr(y), _dt(y), y_ld, layout, N, C, HW, r[2], r[3],
+         1 if relu else 0, _ptr(mask), ctypes.c_float(mask_scale), _stream())
     return y
 
 
@@ -287,9 +301,9 @@ def bn_bwd_local_sums(dz, x, coef, layout, relu, mask=None, mask_scale=1.0):
     _mask_check(mask, x)
     rows = call("segk_bn_stat_rows", layout, N, C, HW)
     partials = torch.empty((rows, 2, C), dtype=torch.float64, device=x.device)
-    call("segk_bn_bwd_stats", _ptr(dz), _dt(dz), dz_ld, _ptr(x), _dt(x), x_ld, layout, N, C, HW, _ptr(coef[0]),
-         _ptr(coef[1]), _ptr(coef[2]), _ptr(coef[3]), 1 if relu else 0, _ptr(mask), ctypes.c_float(mask_scale),
-         _ptr(partials), _stream())
+    r = _row_ptrs(coef)
+    call("segk_bn_bwd_stats", _ptr(dz), _dt(dz), dz_ld, _ptr(x), _dt(x), x_ld, layout, N, C, HW, r[0], r[1], r[2], r[3],
+         1 if relu else 0, _ptr(mask), ctypes.c_float(mask_scale), _ptr(partials), _stream())
     return bn_reduce(partials, float(N * HW))
 
 
@@ -299,9 +313,10 @@ def bn_bwd_apply(dz, x, dx, coef, gsums, layout, relu, mask=None, mask_scale=1.0
     dz_ld = _pm(dz)[0] if layout == PM else 0
     dx_ld = _pm(dx)[0] if layout == PM else 0
     _mask_check(mask, x)
+    r = _row_ptrs(coef)
     call("segk_bn_bwd_apply", _ptr(dz), _dt(dz), dz_ld, _ptr(x), _dt(x), x_ld, _ptr(dx), _dt(dx), dx_ld, layout, N,
-         C, HW, _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]), _ptr(coef[3]), 1 if relu else 0, _ptr(mask),
-         ctypes.c_float(mask_scale), _ptr(gsums), 1 if eval_mode else 0, _stream())
+         C, HW, r[0], r[1], r[2], r[3], 1 if relu else 0, _ptr(mask), ctypes.c_float(mask_scale), _ptr(gsums),
+         1 if eval_mode else 0, _stream())
     return dx
 
 

@@ -43,10 +43,21 @@ def init_from_env(backend=None):
     return dist.get_rank(), dist.get_world_size()
 
 
+def _host_staged(t):
+    """gloo moves bytes over sockets; device tensors are staged through host memory here rather than by
+    gloo's own device path, which stalls intermittently when several ranks share one GPU."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
 def all_reduce_sum_(t):
     """In-place SUM all-reduce on the current stream; identity on one rank."""
     if is_distributed():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if _host_staged(t):
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
 
@@ -94,9 +105,14 @@ class GradientBuckets:
                 else:
                     flat[off:off + n].copy_(p.grad.reshape(-1))
                 off += n
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+            if _host_staged(flat):
+                all_reduce_sum_(flat)
+                works.append(None)
+            else:
+                works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
         for w, flat, bucket in zip(works, flats, self.buckets):
-            w.wait()
+            if w is not None:
+                w.wait()
             off = 0
             for p in bucket:
                 n = p.numel()

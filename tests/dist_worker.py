@@ -152,6 +152,8 @@ def run_gpu(rank, world, outdir):
 def main():
     mode, rank, world, port, outdir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import faulthandler
+    faulthandler.dump_traceback_later(60, exit=True)  # a stuck collective names its call site instead of hanging the test
     if world > 1:
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % port, rank=rank, world_size=world)
     torch.set_num_threads(2)

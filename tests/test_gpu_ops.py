@@ -85,6 +85,10 @@ CONV_CASES = [
 ]
 
 
+# shapes that select the 256x256-tile kernel (>= 512 tiles, Cout a multiple of 256, 128-byte K rows)
+BIG_TILE_CASES = [(1, 256, 257, 64, 512, 3, 2), (2, 181, 182, 128, 256, 1, 1)]
+
+
 def _conv_inputs(case, integer=False):
     N, H, W, Cin, Cout, R, dil = case
     tag = "conv%s" % (case,)
@@ -97,7 +101,7 @@ def _conv_inputs(case, integer=False):
     return T(x), T(w)
 
 
-@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("case", CONV_CASES + BIG_TILE_CASES)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_fwd_exact_integers(ops, case, dtype):
     """Small-integer operands make every product and sum exact in bf16 and fp32: any fragment-layout
@@ -117,7 +121,7 @@ def test_conv_fwd_exact_integers(ops, case, dtype):
     assert torch.equal(s[0], ref.double().sum((0, 2, 3))) and torch.equal(s[1], (ref.double() ** 2).sum((0, 2, 3)))
 
 
-@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("case", CONV_CASES + BIG_TILE_CASES)
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
 def test_conv_fwd_random(ops, case, dtype, tol):
     N, H, W, Cin, Cout, R, dil = case
@@ -219,7 +223,7 @@ def _bn_reference(x, g, b, relu, mask, mask_scale, gy, eps=1e-5):
 
 @pytest.mark.parametrize("layout", ["pm", "nchw"])
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
-@pytest.mark.parametrize("C,shape", [(48, (2, 9, 11)), (256, (3, 7, 5)), (5, (4, 6, 3))])
+@pytest.mark.parametrize("C,shape", [(48, (2, 9, 11)), (256, (3, 7, 5)), (5, (4, 6, 3)), (2048, (2, 5, 3)), (1300, (2, 3, 3))])
 def test_bn_train(ops, layout, dtype, tol, C, shape):
     from segk._lib import NCHW, PM
     if layout == "pm" and C % 4 and dtype == torch.bfloat16:
