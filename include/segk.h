@@ -115,6 +115,78 @@ int segk_conv_wgrad(const segk_wgrad_args* a, segk_stream_t stream);
 int segk_wgrad_finish(const float* slabs, int splits, int R, int Cin, int Cout, float* dw_oihw, int Cout_true,
                       int Cin_true, segk_stream_t stream);
 
+/* ---- batched matrix products (attention: modeling/damm_cam_pam.py) --------------------------- */
+typedef struct {
+  const void* A;     /* [batch][M][lda] */
+  long long a_batch; /* elements between batch entries (0 = shared) */
+  int lda;
+  const void* B;     /* [batch][N][ldb] */
+  long long b_batch;
+  int ldb;
+  int K;             /* contracted length, multiple of 32; both operands hold zeros beyond their true length */
+} segk_gemm_term;
+
+typedef struct {
+  int batch, M, N;
+  int dtype;         /* of every A and B */
+  int nterms;        /* 1..SEGK_MAX_SEG products summed into C */
+  segk_gemm_term term[SEGK_MAX_SEG];
+  void* C;           /* [batch][M][ldc], ldc a multiple of 4 and >= N rounded up to 4 (the rounding columns get zeros) */
+  long long c_batch;
+  int ldc;
+  int c_dtype;
+} segk_gemm_args;
+
+/* C[b][m][n] = sum_t sum_k A_t[b][m][k] * B_t[b][n][k], fp32 accumulation: torch.bmm with the second factor
+ * stored row-major over its contracted index (modeling/damm_cam_pam.py:38,43,83,90 and their gradients). */
+int segk_gemm_nt(const segk_gemm_args* a, segk_stream_t stream);
+
+typedef struct {
+  int batch, M, N, K;
+  int dtype;          /* of A and B */
+  const void* A;      /* [batch][K][lda], M <= lda, M a multiple of 32 (padding columns zero) */
+  long long a_batch;
+  int lda;
+  const void* B;      /* [batch][K][ldb], N <= ldb, N a multiple of 16 */
+  long long b_batch;
+  int ldb;
+  int splits;         /* >= 1 parts of the K range, summed later in index order */
+  float* slabs;       /* [batch][splits][M][N] fp32 */
+} segk_gemm_tn_args;
+
+/* slabs[b][s][m][n] = sum over the s-th part of k of A[b][k][m] * B[b][k][n]: products contracted over the
+ * slow index of both factors (autograd of the torch.bmm calls in modeling/damm_cam_pam.py:38,43,83,90). */
+int segk_gemm_tn(const segk_gemm_tn_args* a, segk_stream_t stream);
+/* C[b][m][n] = sum_s slabs[b][s][m][n] for m < rows, n < cols (rows <= M, cols <= N); C is [batch][rows][ldc]. */
+int segk_gemm_tn_finish(const float* slabs, int batch, int splits, int M, int N, void* C, int c_dtype,
+                        long long c_batch, int ldc, int rows, int cols, segk_stream_t stream);
+
+/* ---- attention helpers (modeling/damm_cam_pam.py) --------------------------------------------- */
+/* Row softmax of fp32 energies e[rows][ld_e] over `cols` columns (nn.Softmax(dim=-1), damm_cam_pam.py:39).
+ * reversed != 0: softmax of (row maximum - e) (damm_cam_pam.py:84-87).  Output columns cols..out_cols are
+ * written as zeros so the result can be contracted over a padded length. */
+int segk_softmax_rows(const float* e, long long rows, int cols, int ld_e, int reversed, void* att, int att_dtype,
+                      int ld_att, int out_cols, segk_stream_t stream);
+/* Gradient of the row softmax w.r.t. its input: de[r][j] = sign * att[r][j] * (datt[r][j] - sum_j' att*datt);
+ * sign = -1 for the reversed form.  Output columns cols..out_cols are zeros. */
+int segk_softmax_rows_bwd(const void* att, int att_dtype, int ld_att, const float* datt, int ld_datt, long long rows,
+                          int cols, float sign, void* de, int de_dtype, int ld_de, int out_cols,
+                          segk_stream_t stream);
+/* dst[b][c][r] = src[b][r][c] for r < R, c < Cc; dst columns R..dst_cols are zeros
+ * (the .view/.permute pairs of damm_cam_pam.py:33-35,41,81-82 on pixel-major data). */
+int segk_transpose(const void* src, int dtype, int batch, int R, int Cc, long long src_batch, int src_ld, void* dst,
+                   long long dst_batch, int dst_ld, int dst_cols, segk_stream_t stream);
+/* out[m][c] = a0*x0 + a1*x1 + a2*x2 with a_i = s_i * (*dev_i) (dev_i NULL = 1): gamma*out + x of
+ * damm_cam_pam.py:46,93 and x1 + x2 of :133 in one pass.  x1/x2 may be NULL.  All operands [M][ld_i], dtype. */
+int segk_lincomb(void* out, int out_dtype, int out_ld, long long M, int C, const void* x0, int ld0, float s0,
+                 const float* dev0, const void* x1, int ld1, float s1, const float* dev1, const void* x2, int ld2,
+                 float s2, const float* dev2, int dtype, segk_stream_t stream);
+/* result[0] = sum over [M][C] of a*b in fp64 order-fixed (gradient of the gamma scalars, damm_cam_pam.py:46,93);
+ * partials: segk_dot_partial_rows(M) doubles. */
+int segk_dot(const void* a, int lda, const void* b, int ldb, int dtype, long long M, int C, double* partials,
+             float* result, segk_stream_t stream);
+int segk_dot_partial_rows(long long M);
+
 /* ---- batch normalisation (synchronized) ----------------------------------------------------- */
 /* Layouts for the BN entry points. */
 typedef enum { SEGK_PM = 0 /* [M][ld], channels contiguous */, SEGK_NCHW = 1 /* [N][C][HW] */ } segk_layout;

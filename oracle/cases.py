@@ -20,7 +20,8 @@ class Impl:
     """Bundle of constructors/functions with the reference's call shapes."""
 
     def __init__(self, Branch, ASPP, Decoder, ce_loss, Evaluator, DeepLab=None, BatchNorm=nn.BatchNorm2d,
-                 interpolate=None, lr_groups=None, device="cpu", name="impl"):
+                 interpolate=None, lr_groups=None, device="cpu", name="impl", PAM=None, CAM=None, DAMM=None,
+                 DeepLabDAMM=None):
         self.Branch = Branch          # (inplanes, planes, k, padding, dilation, BatchNorm)
         self.ASPP = ASPP              # (backbone, output_stride, BatchNorm)
         self.Decoder = Decoder        # (num_classes, backbone, BatchNorm)
@@ -33,6 +34,10 @@ class Impl:
         self.lr_groups = lr_groups    # (model) -> (1x params, 10x params)
         self.device = device
         self.name = name
+        self.PAM = PAM                # (in_dim)
+        self.CAM = CAM                # (in_dim)
+        self.DAMM = DAMM              # (backbone, BatchNorm)
+        self.DeepLabDAMM = DeepLabDAMM  # () -> module (R101 / OS16 / K=8)
 
 
 def _t(a, device, grad=False):
@@ -303,4 +308,72 @@ def case_fullsize(impl, config="A", n=3, backward=True):
         out["d/dec.last0.w"] = _sample(_np(dec.last_conv[0].weight.grad), 4096)
         out["d/dec.cls.b"] = _np(dec.last_conv[8].bias.grad)
         out["d/aspp.bn1.gamma"] = _np(aspp.bn1.weight.grad)
+    return out
+
+
+# ------------------------------------------------------ (10) dual attention ----
+ATT_KINDS = ["pam", "cam"]
+
+
+def _param_grads(m, out, prefix):
+    for name, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        g = _np(p.grad)
+        out[prefix + "d/" + name] = g if g.size <= 4096 else _sample(g)
+
+
+def case_attention(impl, kind, C=64, shape=(3, 7, 9)):
+    """One attention module alone (/root/reference/modeling/damm_cam_pam.py:22-48, :72-94) with gamma != 0
+    (the reference initialises it to 0, which would make the module the identity)."""
+    n, h, w = shape
+    tag = "att_" + kind
+    m = _load(impl.PAM(C) if kind == "pam" else impl.CAM(C), SEED, tag, impl.device)
+    m.train()
+    x = _t(0.5 * gen.normal(SEED, tag + "/x", (n, C, h, w)) * _gain(n, C), impl.device, grad=True)
+    y = m(x)
+    gy = _t(gen.normal(SEED, tag + "/gy", tuple(y.shape)), impl.device)
+    y.backward(gy)
+    out = {"y": _np(y), "dx": _np(x.grad)}
+    _param_grads(m, out, "")
+    return out
+
+
+def case_damm(impl, backbone="ghostnet", shape=(3, 7, 9), inplanes=160):
+    """Both attention modules, their sum and the 1x1 + BN + ReLU behind it (damm_cam_pam.py:130-136)."""
+    n, h, w = shape
+    tag = "damm_" + backbone
+    out = {}
+    for mode in ("train", "eval"):
+        m = _load(impl.DAMM(backbone, impl.BatchNorm), SEED, tag, impl.device)
+        m.train(mode == "train")
+        x = _t(0.5 * gen.relu_normal(SEED, tag + "/x", (n, inplanes, h, w)) * _gain(n, inplanes), impl.device, grad=True)
+        y = m(x)
+        gy = _t(gen.normal(SEED, tag + "/gy", tuple(y.shape)), impl.device)
+        y.backward(gy)
+        out[mode + "_y"] = _np(y)
+        out[mode + "_dx"] = _sample(_np(x.grad), 16384)
+        _param_grads(m, out, mode + "_")
+        if mode == "train":
+            out["train_running_var"] = _np(m.conv1[1].running_var)
+    return out
+
+
+def case_e2e_damm(impl, n=3, size=65, K=8):
+    """Forward, loss and backward of the whole dual-attention DeepLab (/root/reference/modeling/deeplab_damm.py:39-51)."""
+    tag = "e2e_damm"
+    model = _load(impl.DeepLabDAMM(), SEED, tag, impl.device)
+    _zero_dropout(model)
+    model.train()
+    image = _t(gen.normal(SEED, tag + "/img", (n, 3, size, size)) * _gain(n), impl.device)
+    target = _t(gen.labels(SEED, tag + "/lab", (n, size, size), K, border=2), impl.device)
+    output = model(image)
+    loss = impl.ce_loss(output, target, None)
+    loss.backward()
+    out = {"loss": _np(loss).reshape(1), "logits_sample": _sample(_np(output), 8192)}
+    params = dict(model.named_parameters())
+    for name in ("damm.damm1.gamma", "damm.damm2.gamma", "damm.damm1.query_conv.weight", "damm.damm1.value_conv.bias",
+                 "damm.conv1.0.weight", "damm_conv1.0.weight", "damm_conv1.1.weight", "aspp.conv1.weight",
+                 "decoder.last_conv.8.bias", "backbone.layer4.2.conv2.weight", "backbone.conv1.weight"):
+        out["d/" + name] = _sample(_np(params[name].grad), 2048)
     return out

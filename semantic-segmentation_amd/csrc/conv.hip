@@ -32,6 +32,8 @@ struct SegDev {
   const char* w;
   long long in_ld_b;  // bytes between pixels
   long long w_tap_b;  // bytes between taps of the packed weight
+  long long in_batch_b, w_batch_b;  // bytes between the operands of consecutive batch entries (blockIdx.y)
+  int w_ld_b;         // bytes between weight rows (= ck_b for packed weights)
   int ck_b;           // contracted bytes per (pixel, tap)
   int R, dil;
 };
@@ -43,6 +45,7 @@ struct ConvDev {
   SegDev seg[SEGK_MAX_SEG];
   char* out;
   int out_ld;
+  long long out_batch_b;
   const float* bias;
   const float* img_bias;
   double* stat;
@@ -122,6 +125,7 @@ __global__ __launch_bounds__(G::THREADS, (G::THREADS == 256 && G::BCO == 256) ? 
   const long long mt = blockIdx.x / p.n_tiles;
   const int co0 = nt * G::BCO;
   const long long m0 = mt * G::BPX;
+  const long long bz = blockIdx.y;  // batch entry (batched GEMM use; 0 for convolutions)
 
   const int lc = tid % CH, lr = tid / CH;
   int wrow[NPA], ry[NPB], rx[NPB];
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(G::THREADS, (G::THREADS == 256 && G::BCO == 256) ? 
     auto setup_seg = [&]() {
       const SegDev& s = p.seg[sg];
 #pragma unroll
-      for (int i = 0; i < NPA; ++i) aoff[i] = (unsigned)(wrow[i] - co0) * (unsigned)s.ck_b + lc * 16;
+      for (int i = 0; i < NPA; ++i) aoff[i] = (unsigned)(wrow[i] - co0) * (unsigned)s.w_ld_b + lc * 16;
 #pragma unroll
       for (int i = 0; i < NPB; ++i) boff[i] = (unsigned)(rm[i] >= m0 ? rm[i] - m0 : 0) * (unsigned)s.in_ld_b + lc * 16;
     };
@@ -208,8 +212,8 @@ __global__ __launch_bounds__(G::THREADS, (G::THREADS == 256 && G::BCO == 256) ? 
       const int tap = taps_l[sg * 9 + ti];
       const int R = s.R;
       const int dy = (tap / R - (R >> 1)) * s.dil, dx = (tap % R - (R >> 1)) * s.dil;
-      abase = s.w + (long long)tap * s.w_tap_b + (long long)co0 * s.ck_b + (long long)kc * BKB;
-      bbase = s.in + (m0 + (long long)dy * p.W + dx) * s.in_ld_b + (long long)kc * BKB;
+      abase = s.w + bz * s.w_batch_b + (long long)tap * s.w_tap_b + (long long)co0 * s.w_ld_b + (long long)kc * BKB;
+      bbase = s.in + bz * s.in_batch_b + (m0 + (long long)dy * p.W + dx) * s.in_ld_b + (long long)kc * BKB;
 #pragma unroll
       for (int i = 0; i < NPB; ++i)
         bok[i] = rvalid[i] && (unsigned)(ry[i] + dy) < (unsigned)p.H && (unsigned)(rx[i] + dx) < (unsigned)p.W;
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(G::THREADS, (G::THREADS == 256 && G::BCO == 256) ? 
     const long long m = m0 + wc * (MJ * 16) + j * 16 + fr;
     if (m >= p.M) continue;
     const long long n = m / p.HW;
-    char* orow = p.out + (size_t)m * p.out_ld * sizeof(TO);
+    char* orow = p.out + bz * p.out_batch_b + (size_t)m * p.out_ld * sizeof(TO);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int c = co0 + wr * (MI * 16) + i * 16 + fq * 4;
@@ -380,6 +384,7 @@ struct WgradDev {
   int co_tiles, ci_tiles;
   long long per_split;  // pixels per split (multiple of the pixel chunk)
   float* slabs;
+  long long in_batch_b, dout_batch_b;  // batched GEMM use (blockIdx.y); 0 for convolutions
 };
 
 // Tile = [BP pixels][128 channels]; row bytes RB = 128*sizeof(T).
@@ -478,8 +483,9 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_wgrad_kernel(const Wgrad
   const int ch_per_chunk = 16 / esz;
   const bool d_ok = co0 + lc * ch_per_chunk < p.Cout;  // Cout, Cin are multiples of 16 / 32 elements
   const bool x_ok = ci0 + lc * ch_per_chunk < p.Cin;
-  const char* dbase = p.dout + (size_t)(co0 + lc * ch_per_chunk) * esz;
-  const char* xbase = p.in + (size_t)(ci0 + lc * ch_per_chunk) * esz;
+  const long long bz = blockIdx.y;
+  const char* dbase = p.dout + bz * p.dout_batch_b + (size_t)(co0 + lc * ch_per_chunk) * esz;
+  const char* xbase = p.in + bz * p.in_batch_b + (size_t)(ci0 + lc * ch_per_chunk) * esz;
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -553,7 +559,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_wgrad_kernel(const Wgrad
 
   // acc[i][j][r] = dw[co = co0 + wr*64 + i*16 + (lane>>4)*4 + r][ci = ci0 + wc*64 + j*16 + (lane&15)]
   const int fq = lane >> 4, fr = lane & 15;
-  float* slab = p.slabs + ((size_t)sp * taps + tap) * p.Cin * p.Cout;
+  float* slab = p.slabs + (((size_t)bz * p.splits + sp) * taps + tap) * p.Cin * p.Cout;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int ci = ci0 + wc * 64 + j * 16 + fr;
@@ -580,7 +586,7 @@ static int set_lds(K kernel, int bytes, const char* name) {
 }
 
 template <typename T, int BKB, typename TO, typename G, int ABL = 0>
-static int launch_fwd(ConvDev& d, hipStream_t st) {
+static int launch_fwd(ConvDev& d, hipStream_t st, int batch = 1) {
   const int lds = 2 * (G::BCO + G::BPX) * BKB;
   static bool configured = false;  // per instantiation
   if (!configured) {
@@ -594,7 +600,7 @@ static int launch_fwd(ConvDev& d, hipStream_t st) {
     set_error("conv: too many tiles");
     return SEGK_INVALID_ARG;
   }
-  conv_fwd_kernel<T, BKB, TO, G, ABL><<<(int)blocks, G::THREADS, lds, st>>>(d);
+  conv_fwd_kernel<T, BKB, TO, G, ABL><<<dim3((unsigned)blocks, (unsigned)batch), G::THREADS, lds, st>>>(d);
   return SEGK_OK;
 }
 
@@ -649,12 +655,15 @@ static bool fill_dev(const segk_conv_args* a, ConvDev& d) {
     d.seg[s].w = (const char*)g.w;
     d.seg[s].in_ld_b = (long long)g.in_ld * es;
     d.seg[s].ck_b = g.Ck * es;
+    d.seg[s].w_ld_b = g.Ck * es;
+    d.seg[s].in_batch_b = 0;
+    d.seg[s].w_batch_b = 0;
     d.seg[s].w_tap_b = (long long)a->Cout * g.Ck * es;
     d.seg[s].R = g.R;
     d.seg[s].dil = g.dil;
     if (s < a->nseg && (d.seg[s].ck_b % 128) != 0) wide = false;
   }
-  d.out = (char*)a->out; d.out_ld = a->out_ld;
+  d.out = (char*)a->out; d.out_ld = a->out_ld; d.out_batch_b = 0;
   d.bias = a->bias; d.img_bias = a->img_bias; d.stat = a->stat_partials;
   return wide;
 }
@@ -726,6 +735,7 @@ extern "C" int segk_conv_wgrad(const segk_wgrad_args* a, segk_stream_t stream) {
   per = (per + bp - 1) / bp * bp;
   d.per_split = per;
   d.slabs = a->slabs;
+  d.in_batch_b = 0; d.dout_batch_b = 0;
   const long long blocks = (long long)d.co_tiles * d.ci_tiles * a->R * a->R * a->splits;
   SEGK_REQUIRE(blocks < 2147483647LL, "wgrad: too many tiles");
   hipStream_t st = (hipStream_t)stream;
@@ -741,5 +751,108 @@ extern "C" int segk_conv_wgrad(const segk_wgrad_args* a, segk_stream_t stream) {
     conv_wgrad_kernel<float><<<(int)blocks, CONV_THREADS, lds, st>>>(d);
   }
   SEGK_CHECK_LAUNCH("conv_wgrad");
+  return SEGK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched matrix products on the same kernels (attention modules)
+// ------------------------------------------------------------------------------------------------
+extern "C" int segk_gemm_nt(const segk_gemm_args* a, segk_stream_t stream) {
+  SEGK_REQUIRE(a, "gemm_nt: null args");
+  SEGK_REQUIRE(valid_dtype(a->dtype) && valid_dtype(a->c_dtype), "gemm_nt: bad dtype");
+  SEGK_REQUIRE(a->batch > 0 && a->batch <= 65535 && a->M > 0 && a->N > 0, "gemm_nt: bad shape batch=%d M=%d N=%d",
+               a->batch, a->M, a->N);
+  SEGK_REQUIRE(a->nterms >= 1 && a->nterms <= SEGK_MAX_SEG, "gemm_nt: nterms=%d", a->nterms);
+  const int es = dtype_size(a->dtype), cs = dtype_size(a->c_dtype);
+  SEGK_REQUIRE(a->C && a->ldc % 4 == 0 && a->ldc >= ((a->N + 3) & ~3) && ((uintptr_t)a->C % (4 * cs)) == 0 &&
+                   (a->c_batch * cs) % (4 * cs) == 0,
+               "gemm_nt: C must be aligned to 4 elements with ldc a multiple of 4 and >= N rounded up to 4");
+  ConvDev d;
+  d.H = 1; d.W = a->M; d.HW = a->M; d.M = a->M;
+  d.Cout = a->N; d.nseg = a->nterms; d.n_tiles = 0;
+  bool wide = true;
+  for (int s = 0; s < SEGK_MAX_SEG; ++s) {
+    const segk_gemm_term& t = a->term[s < a->nterms ? s : 0];
+    if (s < a->nterms) {
+      SEGK_REQUIRE(t.A && t.B && aligned16(t.A) && aligned16(t.B), "gemm_nt: term %d pointers null or not 16-byte aligned", s);
+      SEGK_REQUIRE(t.K > 0 && t.K % 32 == 0 && t.K <= t.lda && t.K <= t.ldb,
+                   "gemm_nt: term %d K=%d must be a multiple of 32 and <= lda=%d, ldb=%d", s, t.K, t.lda, t.ldb);
+      SEGK_REQUIRE(((long long)t.lda * es) % 16 == 0 && ((long long)t.ldb * es) % 16 == 0 && (t.a_batch * es) % 16 == 0 &&
+                       (t.b_batch * es) % 16 == 0,
+                   "gemm_nt: term %d strides must be multiples of 16 bytes", s);
+      SEGK_REQUIRE((long long)t.ldb * es < 2147483647LL / 256, "gemm_nt: term %d ldb too large", s);
+    }
+    d.seg[s].in = (const char*)t.A;
+    d.seg[s].w = (const char*)t.B;
+    d.seg[s].in_ld_b = (long long)t.lda * es;
+    d.seg[s].w_ld_b = t.ldb * es;
+    d.seg[s].ck_b = t.K * es;
+    d.seg[s].w_tap_b = 0;
+    d.seg[s].in_batch_b = t.a_batch * es;
+    d.seg[s].w_batch_b = t.b_batch * es;
+    d.seg[s].R = 1;
+    d.seg[s].dil = 1;
+    if (s < a->nterms && (d.seg[s].ck_b % 128) != 0) wide = false;
+  }
+  d.out = (char*)a->C; d.out_ld = a->ldc; d.out_batch_b = a->c_batch * cs;
+  d.bias = nullptr; d.img_bias = nullptr; d.stat = nullptr;
+  const long long big_tiles = (long long)ceil_div(a->M, TileBig::BPX) * (a->N / TileBig::BCO) * a->batch;
+  const bool big = wide && a->N % TileBig::BCO == 0 && big_tiles >= 512;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+#define SEGK_LAUNCH(T, TO)                                                                   \
+  (big ? launch_fwd<T, 128, TO, TileBig>(d, st, a->batch)                                    \
+       : (wide ? launch_fwd<T, 128, TO, TileSmall>(d, st, a->batch) : launch_fwd<T, 64, TO, TileSmall>(d, st, a->batch)))
+  if (a->dtype == SEGK_BF16) {
+    rc = a->c_dtype == SEGK_BF16 ? SEGK_LAUNCH(bf16_t, bf16_t) : SEGK_LAUNCH(bf16_t, float);
+  } else {
+    rc = a->c_dtype == SEGK_BF16
+             ? (big ? launch_fwd<float, 128, bf16_t, TileBig>(d, st, a->batch) : launch_fwd<float, 128, bf16_t, TileSmall>(d, st, a->batch))
+             : (big ? launch_fwd<float, 128, float, TileBig>(d, st, a->batch) : launch_fwd<float, 128, float, TileSmall>(d, st, a->batch));
+  }
+#undef SEGK_LAUNCH
+  if (rc != SEGK_OK) return rc;
+  SEGK_CHECK_LAUNCH("gemm_nt");
+  return SEGK_OK;
+}
+
+extern "C" int segk_gemm_tn(const segk_gemm_tn_args* a, segk_stream_t stream) {
+  SEGK_REQUIRE(a && a->A && a->B && a->slabs, "gemm_tn: null pointer");
+  SEGK_REQUIRE(valid_dtype(a->dtype), "gemm_tn: bad dtype");
+  SEGK_REQUIRE(a->batch > 0 && a->batch <= 65535 && a->K > 0 && a->splits >= 1, "gemm_tn: bad shape batch=%d K=%d splits=%d",
+               a->batch, a->K, a->splits);
+  SEGK_REQUIRE(a->M > 0 && a->M % 32 == 0 && a->M <= a->lda, "gemm_tn: M=%d must be a multiple of 32 and <= lda=%d", a->M, a->lda);
+  SEGK_REQUIRE(a->N > 0 && a->N % 16 == 0 && a->N <= a->ldb, "gemm_tn: N=%d must be a multiple of 16 and <= ldb=%d", a->N, a->ldb);
+  const int es = dtype_size(a->dtype);
+  SEGK_REQUIRE(aligned16(a->A) && aligned16(a->B) && aligned16(a->slabs) && ((long long)a->lda * es) % 16 == 0 &&
+                   ((long long)a->ldb * es) % 16 == 0 && (a->a_batch * es) % 16 == 0 && (a->b_batch * es) % 16 == 0,
+               "gemm_tn: operands must be 16-byte aligned with 16-byte multiple strides");
+  WgradDev d;
+  d.H = 1; d.W = a->K; d.HW = a->K; d.M = a->K;
+  d.in = (const char*)a->A; d.dout = (const char*)a->B;
+  d.in_ld_b = (long long)a->lda * es; d.dout_ld_b = (long long)a->ldb * es;
+  d.Cin = a->M; d.Cout = a->N; d.R = 1; d.dil = 1; d.splits = a->splits;
+  d.co_tiles = ceil_div(a->N, TILE); d.ci_tiles = ceil_div(a->M, TILE);
+  const int bp = a->dtype == SEGK_BF16 ? WgFrag<bf16_t>::BP : WgFrag<float>::BP;
+  long long per = ((long long)a->K + a->splits - 1) / a->splits;
+  per = (per + bp - 1) / bp * bp;
+  d.per_split = per;
+  d.slabs = a->slabs;
+  d.in_batch_b = a->a_batch * es; d.dout_batch_b = a->b_batch * es;
+  const long long blocks = (long long)d.co_tiles * d.ci_tiles * a->splits;
+  SEGK_REQUIRE(blocks < 2147483647LL, "gemm_tn: too many tiles");
+  hipStream_t st = (hipStream_t)stream;
+  const int lds = 4 * 16384;
+  int rc;
+  if (a->dtype == SEGK_BF16) {
+    rc = set_lds(conv_wgrad_kernel<bf16_t>, lds, "gemm_tn");
+    if (rc != SEGK_OK) return rc;
+    conv_wgrad_kernel<bf16_t><<<dim3((unsigned)blocks, (unsigned)a->batch), CONV_THREADS, lds, st>>>(d);
+  } else {
+    rc = set_lds(conv_wgrad_kernel<float>, lds, "gemm_tn");
+    if (rc != SEGK_OK) return rc;
+    conv_wgrad_kernel<float><<<dim3((unsigned)blocks, (unsigned)a->batch), CONV_THREADS, lds, st>>>(d);
+  }
+  SEGK_CHECK_LAUNCH("gemm_tn");
   return SEGK_OK;
 }

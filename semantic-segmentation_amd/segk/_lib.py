@@ -33,6 +33,22 @@ class WgradArgs(ctypes.Structure):
                 ("dil", c_int), ("splits", c_int), ("slabs", c_void_p)]
 
 
+class GemmTerm(ctypes.Structure):
+    _fields_ = [("A", c_void_p), ("a_batch", c_ll), ("lda", c_int), ("B", c_void_p), ("b_batch", c_ll), ("ldb", c_int),
+                ("K", c_int)]
+
+
+class GemmArgs(ctypes.Structure):
+    _fields_ = [("batch", c_int), ("M", c_int), ("N", c_int), ("dtype", c_int), ("nterms", c_int),
+                ("term", GemmTerm * MAX_SEG), ("C", c_void_p), ("c_batch", c_ll), ("ldc", c_int), ("c_dtype", c_int)]
+
+
+class GemmTnArgs(ctypes.Structure):
+    _fields_ = [("batch", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("dtype", c_int), ("A", c_void_p),
+                ("a_batch", c_ll), ("lda", c_int), ("B", c_void_p), ("b_batch", c_ll), ("ldb", c_int),
+                ("splits", c_int), ("slabs", c_void_p)]
+
+
 # name -> argument types (every function returns int unless listed in _RESTYPES)
 SIGNATURES = {
     "segk_version": [],
@@ -45,6 +61,17 @@ SIGNATURES = {
     "segk_conv_stat_rows": [ctypes.POINTER(ConvArgs)],
     "segk_conv_wgrad": [ctypes.POINTER(WgradArgs), c_void_p],
     "segk_wgrad_finish": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
+    "segk_gemm_nt": [ctypes.POINTER(GemmArgs), c_void_p],
+    "segk_gemm_tn": [ctypes.POINTER(GemmTnArgs), c_void_p],
+    "segk_gemm_tn_finish": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_ll, c_int, c_int, c_int, c_void_p],
+    "segk_softmax_rows": [c_void_p, c_ll, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
+    "segk_softmax_rows_bwd": [c_void_p, c_int, c_int, c_void_p, c_int, c_ll, c_int, c_float, c_void_p, c_int, c_int,
+                              c_int, c_void_p],
+    "segk_transpose": [c_void_p, c_int, c_int, c_int, c_int, c_ll, c_int, c_void_p, c_ll, c_int, c_int, c_void_p],
+    "segk_lincomb": [c_void_p, c_int, c_int, c_ll, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_int, c_float,
+                     c_void_p, c_void_p, c_int, c_float, c_void_p, c_int, c_void_p],
+    "segk_dot": [c_void_p, c_int, c_void_p, c_int, c_int, c_ll, c_int, c_void_p, c_void_p, c_void_p],
+    "segk_dot_partial_rows": [c_ll],
     "segk_bn_stats": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "segk_bn_stat_rows": [c_int, c_int, c_int, c_int],
     "segk_bn_reduce": [c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p],

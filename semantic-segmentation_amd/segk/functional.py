@@ -512,3 +512,189 @@ class SyncBNFunction(torch.autograd.Function):
         if not ctx.affine:
             dgamma = dbeta = None
         return dx, dgamma, dbeta, None
+
+
+# ------------------------------------------------------------ plain conv ----
+class ConvFunction(torch.autograd.Function):
+    """nn.Conv2d with stride 1, a square kernel and padding = dilation*(k-1)/2 (output size = input size),
+    optional bias: the 1x1 projections of modeling/damm_cam_pam.py:14-16 and the size-preserving part of
+    modeling/deeplab_damm.py:31-32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, dil):
+        cd = config.compute_dtype()
+        N, Cin, H, W = x.shape
+        Cout, R = weight.shape[0], weight.shape[2]
+        xp = _padded_input(to_pm(x, cd))
+        out = torch.empty((N * H * W, ops.round_up(Cout, 4)), dtype=cd, device=x.device)
+        ops.conv_fwd([(xp, ops.pack_weight(weight.detach(), cd), R, dil)], N, H, W, Cout, out,
+                     bias=None if bias is None else bias.detach().float().contiguous(), true_ck=[Cin])
+        ctx.saved = (x, xp, weight, R, dil, (N, H, W), bias is not None)
+        return nchw_view_of(out[:, :Cout] if out.shape[1] != Cout else out, N, H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, xp, weight, R, dil, geom, has_bias = ctx.saved
+        N, H, W = geom
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        gp = _padded_input(to_pm(g, xp.dtype))
+        dw = ops.conv_wgrad(xp, gp, N, H, W, R, dil, Cout, Cin) if ctx.needs_input_grad[1] else None
+        db = ops.pool_sum(gp, 1, N * H * W, 1.0).reshape(-1)[:Cout].contiguous() if has_bias else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxp = dgrad([(gp, weight, R, dil)], geom, Cin, grad_dtype_for(x))
+            dx = grad_like(x, dxp, N, H, W)
+        return dx, dw, db, None
+
+
+def conv2d_same(x, weight, bias=None, dilation=1):
+    return ConvFunction.apply(x, weight, bias, dilation)
+
+
+# ------------------------------------------------------- position attention ----
+def _b3(v, N, P):
+    """[N*P, C] pixel-major view -> [N, P, C] view (no copy)."""
+    return v.unflatten(0, (N, P))
+
+
+class PAMFunction(torch.autograd.Function):
+    """_PAM_Module.forward (modeling/damm_cam_pam.py:22-48): q/k/v 1x1 projections, energy = q^T k per image,
+    row softmax, out = v att^T, gamma*out + x.  Query/key projections and energies stay fp32 whatever the compute
+    dtype (the softmax amplifies operand rounding); the value path runs in the compute dtype."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma):
+        cd = config.compute_dtype()
+        N, C, H, W = x.shape
+        P, M = H * W, N * H * W
+        if C % 32 != 0:
+            raise ValueError("attention modules need a channel count that is a multiple of 32, got %d" % C)
+        Pp = ops.round_up(P, 32)
+        Cq = wq.shape[0]
+        Cqp = ops.round_up(Cq, 32)
+        xp = to_pm(x, cd)
+        f32 = torch.float32
+        alloc = torch.zeros if Cqp != ops.round_up(Cq, 4) else torch.empty
+        qk = alloc((M, 2 * Cqp), dtype=f32, device=x.device)
+        for i, (w, b) in enumerate(((wq, bq), (wk, bk))):
+            ops.conv_fwd([(xp, ops.pack_weight(w.detach(), cd), 1, 1)], N, H, W, Cq, qk[:, i * Cqp:(i + 1) * Cqp],
+                         bias=b.detach().float().contiguous(), true_ck=[C])
+        v = torch.empty((M, C), dtype=cd, device=x.device)
+        ops.conv_fwd([(xp, ops.pack_weight(wv.detach(), cd), 1, 1)], N, H, W, C, v,
+                     bias=bv.detach().float().contiguous(), true_ck=[C])
+        e = torch.empty((N, P, Pp), dtype=f32, device=x.device)
+        ops.gemm_nt([(_b3(qk[:, :Cqp], N, P), _b3(qk[:, Cqp:], N, P))], e, true_k=[Cq])
+        att = torch.empty((N, P, Pp), dtype=cd, device=x.device)
+        ops.softmax_rows(e, P, att)
+        del e
+        vt = torch.empty((N, C, Pp), dtype=cd, device=x.device)
+        ops.transpose(_b3(v, N, P), vt)
+        o = torch.empty((M, C), dtype=cd, device=x.device)
+        ops.gemm_nt([(att, vt)], _b3(o, N, P), true_k=[P])
+        del vt
+        out = torch.empty((M, C), dtype=cd, device=x.device)
+        gdev = gamma.detach().float().reshape(1)
+        ops.lincomb(out, [(o, 1.0, gdev), (xp, 1.0, None)])
+        ctx.saved = (x, xp, qk, v, att, o, wq, wk, wv, gdev, (N, H, W), Cq, Cqp, Pp)
+        return nchw_view_of(out, N, H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, xp, qk, v, att, o, wq, wk, wv, gdev, geom, Cq, Cqp, Pp = ctx.saved
+        N, H, W = geom
+        P, M, C = H * W, N * H * W, xp.shape[1]
+        cd, f32, dev = xp.dtype, torch.float32, xp.device
+        gp = to_pm(g, cd)
+        dgamma = ops.dot(gp, o)
+        do = torch.empty((M, C), dtype=cd, device=dev)
+        ops.lincomb(do, [(gp, 1.0, gdev)])
+        do3 = _b3(do, N, P)
+        datt = torch.empty((N, P, Pp), dtype=f32, device=dev)
+        ops.gemm_nt([(do3, _b3(v, N, P))], datt, true_k=[C])
+        # gradient buffer of the three projections: [dq | dk | dv], padded slices zero
+        dqkv = torch.zeros((M, 2 * Cqp + C), dtype=cd, device=dev)
+        ops.gemm_tn(att, do3, _b3(dqkv[:, 2 * Cqp:], N, P), rows=P, cols=C, true_k=P)
+        de = torch.empty((N, P, Pp), dtype=f32, device=dev)
+        ops.softmax_rows_bwd(att, datt, P, de, 1.0)
+        del datt
+        q3, k3 = _b3(qk[:, :Cqp], N, P), _b3(qk[:, Cqp:], N, P)
+        kt = torch.empty((N, Cqp, Pp), dtype=f32, device=dev)
+        ops.transpose(k3, kt)
+        ops.gemm_nt([(de, kt)], _b3(dqkv[:, :Cqp], N, P), true_k=[P])
+        ops.gemm_tn(de, q3, _b3(dqkv[:, Cqp:2 * Cqp], N, P), rows=P, cols=Cqp, true_k=P)
+        del de, kt
+        sl = (dqkv[:, :Cqp], dqkv[:, Cqp:2 * Cqp], dqkv[:, 2 * Cqp:])
+        grads = []
+        for s, w in zip(sl, (wq, wk, wv)):
+            co = w.shape[0]
+            grads.append(ops.conv_wgrad(xp, s, N, H, W, 1, 1, co, C))
+            grads.append(ops.pool_sum(s, 1, M, 1.0).reshape(-1)[:co].contiguous())
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxa = dgrad([(sl[0], wq, 1, 1), (sl[1], wk, 1, 1), (sl[2], wv, 1, 1)], geom, C, cd)
+            dxp = torch.empty((M, C), dtype=grad_dtype_for(x), device=dev)
+            ops.lincomb(dxp, [(dxa, 1.0, None), (gp, 1.0, None)])
+            dx = grad_like(x, dxp, N, H, W)
+        return (dx,) + tuple(grads) + (dgamma,)
+
+
+# -------------------------------------------------------- channel attention ----
+class CAMFunction(torch.autograd.Function):
+    """_CAM_Module.forward (modeling/damm_cam_pam.py:72-94): energy = x x^T over pixels per image ([C,C]),
+    softmax of (row max - energy), out = att x, gamma*out + x.  Energies are accumulated and normalised in fp32."""
+
+    @staticmethod
+    def forward(ctx, x, gamma):
+        cd = config.compute_dtype()
+        N, C, H, W = x.shape
+        P, M = H * W, N * H * W
+        if C % 32 != 0:
+            raise ValueError("attention modules need a channel count that is a multiple of 32, got %d" % C)
+        Pp = ops.round_up(P, 32)
+        xp = to_pm(x, cd)
+        x3 = _b3(xp, N, P)
+        xt = torch.empty((N, C, Pp), dtype=cd, device=x.device)
+        ops.transpose(x3, xt)
+        e = torch.empty((N, C, C), dtype=torch.float32, device=x.device)
+        ops.gemm_nt([(xt, xt)], e, true_k=[P])
+        del xt
+        att = torch.empty((N, C, C), dtype=cd, device=x.device)
+        ops.softmax_rows(e, C, att, reversed_=True)
+        del e
+        o = torch.empty((M, C), dtype=cd, device=x.device)
+        ops.gemm_nt([(x3, att)], _b3(o, N, P), true_k=[C])
+        out = torch.empty((M, C), dtype=cd, device=x.device)
+        gdev = gamma.detach().float().reshape(1)
+        ops.lincomb(out, [(o, 1.0, gdev), (xp, 1.0, None)])
+        ctx.saved = (x, xp, att, o, gdev, (N, H, W))
+        return nchw_view_of(out, N, H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, xp, att, o, gdev, geom = ctx.saved
+        N, H, W = geom
+        P, M, C = H * W, N * H * W, xp.shape[1]
+        cd, dev = xp.dtype, xp.device
+        gp = to_pm(g, cd)
+        dgamma = ops.dot(gp, o)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            do = torch.empty((M, C), dtype=cd, device=dev)
+            ops.lincomb(do, [(gp, 1.0, gdev)])
+            do3, x3 = _b3(do, N, P), _b3(xp, N, P)
+            datt = torch.empty((N, C, C), dtype=torch.float32, device=dev)
+            ops.gemm_tn(do3, x3, datt, true_k=P)
+            de = torch.empty((N, C, C), dtype=cd, device=dev)
+            ops.softmax_rows_bwd(att, datt, C, de, -1.0)
+            del datt
+            att_t = torch.empty((N, C, C), dtype=cd, device=dev)
+            ops.transpose(att, att_t)
+            de_t = torch.empty((N, C, C), dtype=cd, device=dev)
+            ops.transpose(de, de_t)
+            dxa = torch.empty((M, C), dtype=cd, device=dev)
+            ops.gemm_nt([(do3, att_t), (x3, de), (x3, de_t)], _b3(dxa, N, P), true_k=[C, C, C])
+            del att_t, de_t, de
+            dxp = torch.empty((M, C), dtype=grad_dtype_for(x), device=dev)
+            ops.lincomb(dxp, [(dxa, 1.0, None), (gp, 1.0, None)])
+            dx = grad_like(x, dxp, N, H, W)
+        return dx, dgamma

@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, NCHW, PM, ConvArgs, WgradArgs, call
+from ._lib import BF16, F32, NCHW, PM, ConvArgs, GemmArgs, GemmTnArgs, WgradArgs, call
 
 
 def _dt(t):
@@ -213,6 +213,161 @@ def conv_wgrad(x, dout, N, H, W, R, dil, Cout_true, Cin_true, splits=None):
     dw = torch.empty((Cout_true, Cin_true, R, R), dtype=torch.float32, device=x.device)
     call("segk_wgrad_finish", _ptr(slabs), splits, R, Cin, Cout, _ptr(dw), Cout_true, Cin_true, _stream())
     return dw
+
+
+# ---------------------------------------------------- batched matrix products ----
+def _b3(t, name):
+    """(batch stride, leading dimension) of a [batch, rows, cols] view with unit column stride."""
+    if t.dim() != 3 or t.stride(2) != 1:
+        raise ValueError("%s must be a 3-D view [batch, rows, cols] with unit column stride, got shape %s strides %s"
+                         % (name, tuple(t.shape), t.stride()))
+    return t.stride(0), t.stride(1)
+
+
+def gemm_nt(terms, out, true_k=None):
+    """out[b] = sum_t A_t[b] @ B_t[b]^T.  terms: list of (A [b|1, M, K], B [b|1, N, K]); K a multiple of 32 with
+    zeros beyond the true contracted length in both factors; a leading dimension of 1 is shared by the batch.
+    out: [b, M, N'] view, N' >= N rounded up to 4 (rounding columns receive zeros)."""
+    _dev(out)
+    c_batch, ldc = _b3(out, "out")
+    batch, M = out.shape[0], out.shape[1]
+    a = GemmArgs()
+    a.batch, a.M, a.nterms = batch, M, len(terms)
+    if not 1 <= len(terms) <= _lib.MAX_SEG:
+        raise ValueError("1..%d terms" % _lib.MAX_SEG)
+    N, dt, flops = None, None, 0.0
+    for i, (A, B) in enumerate(terms):
+        _dev(A, B)
+        ab, lda = _b3(A, "A")
+        bb, ldb = _b3(B, "B")
+        if A.dtype != B.dtype or (dt is not None and A.dtype != dt):
+            raise ValueError("all gemm operands share one dtype")
+        dt = A.dtype
+        if A.shape[1] != M or A.shape[2] != B.shape[2] or (N is not None and B.shape[1] != N):
+            raise ValueError("term %d shapes %s x %s do not match M=%d N=%s" % (i, tuple(A.shape), tuple(B.shape), M, N))
+        N = B.shape[1]
+        for t, nm in ((A, "A"), (B, "B")):
+            if t.shape[0] not in (1, batch):
+                raise ValueError("term %d %s has batch %d, expected 1 or %d" % (i, nm, t.shape[0], batch))
+        tm = a.term[i]
+        tm.A, tm.a_batch, tm.lda = A.data_ptr(), (ab if A.shape[0] == batch and batch > 1 else 0), lda
+        tm.B, tm.b_batch, tm.ldb = B.data_ptr(), (bb if B.shape[0] == batch and batch > 1 else 0), ldb
+        tm.K = A.shape[2]
+        flops += 2.0 * batch * M * N * (true_k[i] if true_k is not None else A.shape[2])
+    if out.shape[2] < round_up(N, 4) and ldc < round_up(N, 4):
+        raise ValueError("out has %d columns, needs %d" % (out.shape[2], round_up(N, 4)))
+    a.N, a.dtype = N, _dt(terms[0][0])
+    a.C, a.c_batch, a.ldc, a.c_dtype = out.data_ptr(), (c_batch if batch > 1 else 0), ldc, _dt(out)
+    t0 = TIMER.start() if TIMER is not None else None
+    call("segk_gemm_nt", ctypes.byref(a), _stream())
+    if t0 is not None:
+        TIMER.stop("conv_fwd_kernel", flops, t0)
+    return out
+
+
+def gemm_tn(A, B, out, rows=None, cols=None, splits=1, true_k=None):
+    """out[b][m][n] = sum_k A[b][k][m] * B[b][k][n] for m < rows, n < cols.  A: [b, K, Mp], B: [b, K, Np] views
+    (Mp a multiple of 32, Np of 16, padding columns zero).  out: [b, rows, >=cols] view of any supported dtype."""
+    _dev(A, B, out)
+    ab, lda = _b3(A, "A")
+    bb, ldb = _b3(B, "B")
+    cb, ldc = _b3(out, "out")
+    batch, K, Mp = A.shape
+    Np = B.shape[2]
+    if B.shape[0] != batch or B.shape[1] != K or out.shape[0] != batch or A.dtype != B.dtype:
+        raise ValueError("gemm_tn operands disagree: %s %s %s" % (tuple(A.shape), tuple(B.shape), tuple(out.shape)))
+    rows = out.shape[1] if rows is None else rows
+    cols = out.shape[2] if cols is None else cols
+    direct = (splits == 1 and out.dtype == torch.float32 and out.is_contiguous() and out.shape[1] == Mp
+              and out.shape[2] == Np and rows == Mp and cols == Np)
+    slabs = out if direct else torch.empty((batch, splits, Mp, Np), dtype=torch.float32, device=A.device)
+    a = GemmTnArgs()
+    a.batch, a.M, a.N, a.K, a.dtype = batch, Mp, Np, K, _dt(A)
+    a.A, a.a_batch, a.lda = A.data_ptr(), (ab if batch > 1 else 0), lda
+    a.B, a.b_batch, a.ldb = B.data_ptr(), (bb if batch > 1 else 0), ldb
+    a.splits, a.slabs = splits, slabs.data_ptr()
+    t0 = TIMER.start() if TIMER is not None else None
+    call("segk_gemm_tn", ctypes.byref(a), _stream())
+    if t0 is not None:
+        TIMER.stop("conv_wgrad_kernel", 2.0 * batch * rows * cols * (true_k if true_k is not None else K), t0)
+    if not direct:
+        call("segk_gemm_tn_finish", _ptr(slabs), batch, splits, Mp, Np, _ptr(out), _dt(out), (cb if batch > 1 else 0),
+             ldc, rows, cols, _stream())
+    return out
+
+
+def softmax_rows(e, cols, out, reversed_=False):
+    """e: contiguous float32 [..., ld]; softmax over the first `cols` columns of every row into out [..., ld_out]
+    (columns cols.. of out are zero-filled).  reversed_: softmax(row max - e)."""
+    _dev(e, out)
+    if e.dtype != torch.float32 or not e.is_contiguous() or not out.is_contiguous():
+        raise ValueError("softmax_rows expects contiguous tensors and float32 energies")
+    rows = e.numel() // e.shape[-1]
+    if out.numel() // out.shape[-1] != rows:
+        raise ValueError("row counts differ")
+    call("segk_softmax_rows", _ptr(e), rows, cols, e.shape[-1], 1 if reversed_ else 0, _ptr(out), _dt(out),
+         out.shape[-1], out.shape[-1], _stream())
+    return out
+
+
+def softmax_rows_bwd(att, datt, cols, out, sign=1.0):
+    _dev(att, datt, out)
+    if datt.dtype != torch.float32 or not (att.is_contiguous() and datt.is_contiguous() and out.is_contiguous()):
+        raise ValueError("softmax_rows_bwd expects contiguous tensors and a float32 upstream gradient")
+    rows = att.numel() // att.shape[-1]
+    call("segk_softmax_rows_bwd", _ptr(att), _dt(att), att.shape[-1], _ptr(datt), datt.shape[-1], rows, cols,
+         ctypes.c_float(sign), _ptr(out), _dt(out), out.shape[-1], out.shape[-1], _stream())
+    return out
+
+
+def transpose(src, out):
+    """out[b][c][r] = src[b][r][c]; src [b, R, C] view, out [b, C, >=R] view whose extra columns get zeros."""
+    _dev(src, out)
+    sb, sld = _b3(src, "src")
+    ob, old = _b3(out, "out")
+    batch, R, C = src.shape
+    if out.shape[0] != batch or out.shape[1] != C or out.shape[2] < R or src.dtype != out.dtype:
+        raise ValueError("transpose shapes disagree: %s -> %s" % (tuple(src.shape), tuple(out.shape)))
+    call("segk_transpose", _ptr(src), _dt(src), batch, R, C, (sb if batch > 1 else 0), sld, _ptr(out),
+         (ob if batch > 1 else 0), old, out.shape[2], _stream())
+    return out
+
+
+def lincomb(out, terms):
+    """out = sum_i s_i * dev_i * x_i over pixel-major views; terms: up to three (x, s, dev) with dev a 1-element
+    float32 device tensor or None."""
+    _dev(out)
+    old, C = _pm(out)
+    M = out.shape[0]
+    args = []
+    dt = terms[0][0].dtype
+    for x, s, dev in terms:
+        _dev(x, dev)
+        ld, c = _pm(x)
+        if c != C or x.shape[0] != M or x.dtype != dt:
+            raise ValueError("lincomb operands disagree")
+        if dev is not None and (dev.dtype != torch.float32 or dev.numel() != 1):
+            raise ValueError("device scalars are 1-element float32 tensors")
+        args += [_ptr(x), ld, ctypes.c_float(s), _ptr(dev)]
+    for _ in range(3 - len(terms)):
+        args += [None, 0, ctypes.c_float(0.0), None]
+    call("segk_lincomb", _ptr(out), _dt(out), old, M, C, *args, _dt(terms[0][0]), _stream())
+    return out
+
+
+def dot(a, b):
+    """sum(a * b) over two pixel-major views of one dtype -> 1-element float32 device tensor."""
+    _dev(a, b)
+    lda, C = _pm(a)
+    ldb, Cb = _pm(b)
+    if C != Cb or a.shape[0] != b.shape[0] or a.dtype != b.dtype:
+        raise ValueError("dot operands disagree")
+    M = a.shape[0]
+    rows = call("segk_dot_partial_rows", M)
+    partials = torch.empty((rows,), dtype=torch.float64, device=a.device)
+    res = torch.empty((1,), dtype=torch.float32, device=a.device)
+    call("segk_dot", _ptr(a), lda, _ptr(b), ldb, _dt(a), M, C, _ptr(partials), _ptr(res), _stream())
+    return res
 
 
 # ---------------------------------------------------------------------- BN ----

@@ -381,3 +381,130 @@ def test_argmax_and_confmat_bit_exact(ops, K):
     ops.confmat_accumulate(gt_i, bad, K, cm)
     valid7 = 0 <= gt_np.reshape(-1)[7] < K
     assert int(cm[-1]) == (1 if valid7 else 0)
+
+
+# ------------------------------------------------- batched matrix products ----
+GEMM_CASES = [  # batch, M, N, K (true), Kpad
+    (3, 63, 63, 8, 32),        # position-attention energies of a small map
+    (2, 200, 72, 100, 128),    # ragged everything
+    (2, 961, 256, 992, 992),   # config-E sized rows, full 128-byte K rows
+    (1, 300, 512, 64, 64),
+]
+
+
+def _int_operand(tag, shape, kpad, dtype):
+    """Small integers (exact in bf16 and in any fp32 summation order) in a zero-padded [.., kpad] buffer."""
+    v = gen.integers(3, tag, shape, -3, 4).astype(np.float32)
+    buf = torch.zeros(shape[:-1] + (kpad,), dtype=dtype, device=DEV)
+    buf[..., :shape[-1]] = T(v, dtype)
+    return buf, T(v)
+
+
+@pytest.mark.parametrize("case", GEMM_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_nt_exact_integers(ops, case, dtype):
+    b, M, N, K, Kp = case
+    A, a = _int_operand("gA%d" % M, (b, M, K), Kp, dtype)
+    B, bm = _int_operand("gB%d" % N, (b, N, K), Kp, dtype)
+    ldc = (N + 3) // 4 * 4 + 8
+    out = torch.full((b, M, ldc), 7.0, dtype=torch.float32, device=DEV)
+    ops.gemm_nt([(A, B)], out[:, :, :(N + 3) // 4 * 4])
+    assert torch.equal(out[:, :, :N], torch.bmm(a, bm.transpose(1, 2)))
+    assert float(out[:, :, (N + 3) // 4 * 4:].min()) == 7.0  # nothing written beyond the rounded width
+
+
+def test_gemm_nt_terms_shared_operand_and_strided_views(ops):
+    b, M, N, K = 3, 70, 40, 64
+    big = T(gen.integers(3, "gbig", (b * M, 3 * K), -2, 3).astype(np.float32))
+    A1, A2 = big[:, :K].unflatten(0, (b, M)), big[:, 2 * K:].unflatten(0, (b, M))  # column slices, batched view
+    B1 = T(gen.integers(3, "gb1", (b, N, K), -2, 3).astype(np.float32))
+    B2 = T(gen.integers(3, "gb2", (1, N, K), -2, 3).astype(np.float32))            # shared by the batch
+    out = torch.empty((b, M, N), dtype=torch.float32, device=DEV)
+    ops.gemm_nt([(A1, B1), (A2, B2)], out)
+    want = torch.bmm(A1, B1.transpose(1, 2)) + torch.matmul(A2, B2[0].t())
+    assert torch.equal(out, want)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+def test_gemm_nt_random(ops, dtype, tol):
+    b, M, N, K = 2, 130, 96, 160
+    A = T(gen.normal(4, "rA", (b, M, K)), dtype)
+    B = T(gen.normal(4, "rB", (b, N, K)), dtype)
+    out = torch.empty((b, M, N), dtype=dtype, device=DEV)
+    ops.gemm_nt([(A, B)], out)
+    assert relerr(out, torch.bmm(A.float(), B.float().transpose(1, 2))) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("splits", [1, 3])
+def test_gemm_tn_exact_integers(ops, dtype, splits):
+    b, K, M, N = 3, 63, 64, 48          # padded widths; true rows/cols below
+    rows, cols = 63, 40
+    A = torch.zeros((b, K, M), dtype=dtype, device=DEV)
+    B = torch.zeros((b, K, N), dtype=dtype, device=DEV)
+    a = T(gen.integers(5, "tA", (b, K, rows), -3, 4).astype(np.float32))
+    bm = T(gen.integers(5, "tB", (b, K, cols), -3, 4).astype(np.float32))
+    A[:, :, :rows], B[:, :, :cols] = a.to(dtype), bm.to(dtype)
+    wide = torch.full((b, rows, cols + 8), 7.0, dtype=dtype, device=DEV)
+    ops.gemm_tn(A, B, wide[:, :, :cols], rows=rows, cols=cols, splits=splits)
+    assert torch.equal(wide[:, :, :cols].float(), torch.bmm(a.transpose(1, 2), bm))
+    assert float(wide[:, :, cols:].float().min()) == 7.0
+    if splits == 1:
+        dense = torch.empty((b, M, N), dtype=torch.float32, device=DEV)   # written by the kernel itself
+        ops.gemm_tn(A, B, dense)
+        assert torch.equal(dense[:, :rows, :cols], torch.bmm(a.transpose(1, 2), bm))
+        assert float(dense[:, rows:].abs().sum()) == 0 and float(dense[:, :, cols:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("reversed_", [False, True])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("rows,cols,ld", [(7, 63, 64), (5, 961, 992), (3, 2048, 2048), (4, 300, 320)])
+def test_softmax_rows_and_gradient(ops, reversed_, dtype, tol, rows, cols, ld):
+    e = torch.full((rows, ld), float("nan"), dtype=torch.float32, device=DEV)   # padding must not be read
+    ev = T(3.0 * gen.normal(6, "sm%d" % cols, (rows, cols)))
+    e[:, :cols] = ev
+    att = torch.full((rows, ld), 9.0, dtype=dtype, device=DEV)
+    ops.softmax_rows(e, cols, att, reversed_=reversed_)
+    z = (ev.max(-1, keepdim=True)[0] - ev) if reversed_ else ev
+    want = torch.softmax(z.double(), -1)
+    assert relerr(att[:, :cols], want) < tol
+    assert float(att[:, cols:].float().abs().sum()) == 0
+    # gradient w.r.t. e for upstream gradient g on att (the stored, possibly rounded, att is what backward uses)
+    g = torch.zeros((rows, ld), dtype=torch.float32, device=DEV)
+    gv = T(gen.normal(6, "smg%d" % cols, (rows, cols)))
+    g[:, :cols] = gv
+    de = torch.full((rows, ld), 9.0, dtype=dtype, device=DEV)
+    ops.softmax_rows_bwd(att, g, cols, de, -1.0 if reversed_ else 1.0)
+    a = att[:, :cols].double()
+    want_de = a * (gv.double() - (a * gv.double()).sum(-1, keepdim=True)) * (-1.0 if reversed_ else 1.0)
+    assert relerr(de[:, :cols], want_de) < max(tol, 1e-5)
+    assert float(de[:, cols:].float().abs().sum()) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_transpose_batched_padded(ops, dtype):
+    b, R, C = 3, 63, 200
+    wide = T(gen.normal(7, "tr", (b * R, C + 24)), dtype)
+    src = wide[:, 8:8 + C].unflatten(0, (b, R))
+    out = torch.full((b, C, 96), 5.0, dtype=dtype, device=DEV)
+    ops.transpose(src, out)
+    assert torch.equal(out[:, :, :R], src.transpose(1, 2))
+    assert float(out[:, :, R:].float().abs().sum()) == 0
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1e-2)])
+def test_lincomb_and_dot(ops, dtype, tol):
+    M, C = 500, 160
+    x = T(gen.normal(8, "lx", (M, C + 32)), dtype)[:, 16:16 + C]
+    y = T(gen.normal(8, "ly", (M, C)), dtype)
+    z = T(gen.normal(8, "lz", (M, C)), dtype)
+    s = T(np.array([0.7], dtype=np.float32))
+    out = torch.empty((M, C), dtype=torch.float32, device=DEV)
+    ops.lincomb(out, [(x, 1.0, s), (y, 2.0, None), (z, -1.0, s)])
+    want = 0.7 * x.double() + 2.0 * y.double() - 0.7 * z.double()
+    assert relerr(out, want) < 1e-6
+    out2 = torch.empty((M, C), dtype=dtype, device=DEV)
+    ops.lincomb(out2, [(x, 1.0, s)])
+    assert relerr(out2, 0.7 * x.double()) < tol
+    d = ops.dot(x, y)
+    assert abs(float(d) - float((x.double() * y.double()).sum())) < 1e-5 * float((x.double() * y.double()).abs().sum())

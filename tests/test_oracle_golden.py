@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from helpers import assert_dicts_close, load_golden
-from oracle import cases, gen, head_ref, ops_ref
+from oracle import cases, damm_ref, gen, head_ref, ops_ref
 
 TOL = 2e-5
 
@@ -22,7 +22,9 @@ def oracle_impl():
     return cases.Impl(Branch=head_ref.RefBranch, ASPP=head_ref.RefASPP, Decoder=head_ref.RefDecoder, ce_loss=ce,
                       Evaluator=ops_ref.RefEvaluator,
                       DeepLab=lambda: head_ref.RefDeepLab("resnet", 16, 21, nn.BatchNorm2d),
-                      lr_groups=lambda m: m.lr_groups(), name="oracle")
+                      lr_groups=lambda m: m.lr_groups(), name="oracle", PAM=damm_ref.RefPAM, CAM=damm_ref.RefCAM,
+                      DAMM=damm_ref.RefDAMM,
+                      DeepLabDAMM=lambda: damm_ref.RefDeepLabDAMM("resnet", 16, 8, nn.BatchNorm2d))
 
 
 @pytest.fixture(scope="module")
@@ -101,6 +103,19 @@ def test_e2e_two_sgd_steps(impl):
     want = load_golden("e2e")
     assert_dicts_close(got, want, 1e-4, exact=())
     assert np.array_equal(got["cm"], want["cm"])
+
+
+@pytest.mark.parametrize("kind", cases.ATT_KINDS)
+def test_attention(impl, kind):
+    assert_dicts_close(cases.case_attention(impl, kind), load_golden("att_" + kind), TOL)
+
+
+def test_damm(impl):
+    assert_dicts_close(cases.case_damm(impl), load_golden("damm_ghostnet"), TOL)
+
+
+def test_e2e_damm(impl):
+    assert_dicts_close(cases.case_e2e_damm(impl), load_golden("e2e_damm"), 1e-4)
 
 
 @pytest.mark.slow
