@@ -339,19 +339,20 @@ def case_attention(impl, kind, C=64, shape=(3, 7, 9)):
     return out
 
 
-def case_damm(impl, backbone="ghostnet", shape=(3, 7, 9), inplanes=160):
+def case_damm(impl, backbone="ghostnet", shape=(3, 7, 9), inplanes=160, modes=("train", "eval")):
     """Both attention modules, their sum and the 1x1 + BN + ReLU behind it (damm_cam_pam.py:130-136)."""
     n, h, w = shape
     tag = "damm_" + backbone
     out = {}
-    for mode in ("train", "eval"):
+    for mode in modes:
         m = _load(impl.DAMM(backbone, impl.BatchNorm), SEED, tag, impl.device)
         m.train(mode == "train")
         x = _t(0.5 * gen.relu_normal(SEED, tag + "/x", (n, inplanes, h, w)) * _gain(n, inplanes), impl.device, grad=True)
         y = m(x)
         gy = _t(gen.normal(SEED, tag + "/gy", tuple(y.shape)), impl.device)
         y.backward(gy)
-        out[mode + "_y"] = _np(y)
+        yn = _np(y)
+        out[mode + "_y"] = yn if yn.size <= 65536 else _sample(yn, 16384)
         out[mode + "_dx"] = _sample(_np(x.grad), 16384)
         _param_grads(m, out, mode + "_")
         if mode == "train":

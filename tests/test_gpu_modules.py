@@ -321,6 +321,20 @@ def test_damm_bf16(impl):
         assert rel_err(got[k], want[k]) < 1e-1, k
 
 
+def test_damm_config_E_size(impl):
+    """The attention branch at its BASELINE size (2048 channels, 31 x 31 map, K = 961 / 2048 row softmaxes)."""
+    kw = dict(shape=(2, 31, 31), inplanes=2048, modes=("train",))
+    gold = load_golden("damm_resnet_E")
+    skip = KEY_BIAS + VALUE_BIAS_TRAIN
+    got, want = matched(cases.case_damm, impl, "cuda", "resnet", **kw)
+    assert_dicts_close(forward_only(got), forward_only(gold), FWD)
+    # the oracle runs on the GPU here (MIOpen / rocBLAS, about 2e-4 from exact fp32): gradients 2e-3
+    assert_dicts_close(got, want, FWD, 2e-3, skip=skip)
+    got, want = matched(cases.case_damm, impl, "cuda", "resnet", dtype=torch.bfloat16, **kw)
+    assert_dicts_close(forward_only(got), forward_only(gold), BF)
+    assert_dicts_close(got, want, BF, BF, skip=skip + GAMMA_TRAIN)
+
+
 def test_e2e_damm_fp32(impl):
     """Whole dual-attention DeepLab: loss against the reference's golden; gradients against feeder + oracle head
     on the same activation pattern (head and attention parameters 1e-3, feeder by L2 as in the plain e2e test)."""
