@@ -103,6 +103,86 @@ struct TileCfg {
 typedef TileCfg<128, 128, 2, 2> TileSmall;
 typedef TileCfg<256, 256, 4, 2> TileBig;
 
+// Epilogue shared by the forward kernels: optional fp64 batch-norm statistics of the unbiased accumulators, then
+// bias / per-image bias and the store.  acc[i][j][r] = out[pixel = wc*MJ*16 + j*16 + (lane&15)]
+//                                                         [co = wr*MI*16 + i*16 + (lane>>4)*4 + r]
+template <typename TO, typename G>
+__device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x4 (&acc)[G::MI][G::MJ], char* smem, int wr, int wc,
+                                              int lane, int tid, int co0, long long m0, long long mt, long long bz) {
+  constexpr int MI = G::MI, MJ = G::MJ, NT = G::THREADS;
+  const int fq = lane >> 4, fr = lane & 15;
+  if (p.stat) {
+    // fp64 sums: the squares of the fp32 accumulators are exact in fp64
+    double* red = reinterpret_cast<double*>(smem);  // [WPX pixel parts][2][BCO]
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      double s[4], q[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[r] = 0.0;
+        q[r] = 0.0;
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+          const double v = (double)acc[i][j][r];
+          s[r] += v;
+          q[r] = fma(v, v, q[r]);
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          s[r] += __shfl_xor(s[r], o, 64);
+          q[r] += __shfl_xor(q[r], o, 64);
+        }
+      }
+      if (fr == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cl = wr * (MI * 16) + i * 16 + fq * 4 + r;
+          red[(wc * 2 + 0) * G::BCO + cl] = s[r];
+          red[(wc * 2 + 1) * G::BCO + cl] = q[r];
+        }
+      }
+    }
+    __syncthreads();
+    for (int t = tid; t < 2 * G::BCO; t += NT) {
+      const int which = t / G::BCO, cl = t % G::BCO;
+      const int co = co0 + cl;
+      if (co < p.Cout) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < G::WPX; ++w) v += red[(w * 2 + which) * G::BCO + cl];
+        p.stat[((size_t)mt * 2 + which) * p.Cout + co] = v;
+      }
+    }
+  }
+
+  const int cpad = (p.Cout + 3) & ~3;
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) {
+    const long long m = m0 + wc * (MJ * 16) + j * 16 + fr;
+    if (m >= p.M) continue;
+    const long long n = m / p.HW;
+    char* orow = p.out + bz * p.out_batch_b + (size_t)m * p.out_ld * sizeof(TO);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int c = co0 + wr * (MI * 16) + i * 16 + fq * 4;
+      if (c >= cpad) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = acc[i][j][r];
+        if (c + r < p.Cout) {
+          if (p.bias) t += p.bias[c + r];
+          if (p.img_bias) t += p.img_bias[n * p.Cout + c + r];
+        } else {
+          t = 0.f;
+        }
+        v[r] = t;
+      }
+      store_out4<TO>(orow + (size_t)c * sizeof(TO), v);
+    }
+  }
+}
+
 template <typename T, int BKB, typename TO, typename G, int ABL = 0>
 __global__ __launch_bounds__(G::THREADS, (G::THREADS == 256 && G::BCO == 256) ? 1 : 2) void conv_fwd_kernel(const ConvDev p) {
   constexpr int NT = G::THREADS;
@@ -297,78 +377,297 @@ __global__ __launch_bounds__(G::THREADS, (G::THREADS == 256 && G::BCO == 256) ? 
     }
   }
 
-  // ---- epilogue: acc[i][j][r] = out[pixel = wc*MJ*16 + j*16 + (lane&15)][co = wr*MI*16 + i*16 + (lane>>4)*4 + r]
-  const int fq = lane >> 4, fr = lane & 15;
-  if (p.stat) {
-    // fp64 sums: the squares of the fp32 accumulators are exact in fp64
-    double* red = reinterpret_cast<double*>(smem);  // [WPX pixel parts][2][BCO]
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      double s[4], q[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s[r] = 0.0;
-        q[r] = 0.0;
-#pragma unroll
-        for (int j = 0; j < MJ; ++j) {
-          const double v = (double)acc[i][j][r];
-          s[r] += v;
-          q[r] = fma(v, v, q[r]);
-        }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          s[r] += __shfl_xor(s[r], o, 64);
-          q[r] += __shfl_xor(q[r], o, 64);
-        }
-      }
-      if (fr == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int cl = wr * (MI * 16) + i * 16 + fq * 4 + r;
-          red[(wc * 2 + 0) * G::BCO + cl] = s[r];
-          red[(wc * 2 + 1) * G::BCO + cl] = q[r];
-        }
-      }
-    }
-    __syncthreads();
-    for (int t = tid; t < 2 * G::BCO; t += NT) {
-      const int which = t / G::BCO, cl = t % G::BCO;
-      const int co = co0 + cl;
-      if (co < p.Cout) {
-        double v = 0.0;
-#pragma unroll
-        for (int w = 0; w < G::WPX; ++w) v += red[(w * 2 + which) * G::BCO + cl];
-        p.stat[((size_t)mt * 2 + which) * p.Cout + co] = v;
-      }
-    }
-  }
+  conv_epilogue<TO, G>(p, acc, smem, wr, wc, lane, tid, co0, m0, mt, bz);
+}
 
-  const int cpad = (p.Cout + 3) & ~3;
+// ------------------------------------------------------------------------------------------------
+// Forward / data gradient, deep-pipelined variant: bf16 operands, Cout a multiple of 256, 128-byte K rows.
+//
+// 256(co) x 256(pixel) tile, 8 wavefronts as 2 (co) x 4 (pixel), 128 x 64 per wavefront.  Operands reach LDS by
+// LDS-DMA (global_load_lds_dwordx4: no staging registers) in half-tiles of 128 rows x 128 bytes = 16 KiB; LDS is a
+// ring of 8 such slots.  A K-tile (64 channels of one tap) consists of four half-tiles
+//      A0 / A1 = weight rows {wr*128 + h*64 ..+64}  (the h-th 64-row half of BOTH wavefront rows)
+//      B0 / B1 = pixels      {wc*64  + h*32 ..+32}  (the h-th 32-pixel half of all four wavefront columns)
+// and is consumed in four phases of 16 MFMAs each (one quadrant of the wavefront's 8 x 4 accumulator tiles):
+//      phase 4t+0: read A0(t)           Q00 += A0 x B0(t)
+//      phase 4t+1: read B1(t)           Q01 += A0 x B1
+//      phase 4t+2: read A1(t)           Q11 += A1 x B1
+//      phase 4t+3: read B0(t+1)         Q10 += A1 x B0(t)      (B0 alternates between two register sets)
+// so the half-tile read in phase n sits in ring slot n & 7.  In phase n every wavefront also issues its share
+// (two 1-KiB pieces) of the half-tile that phase n+6 will read, into slot (n-2) & 7, whose last reader was phase
+// n-2; `s_waitcnt vmcnt(10)` then leaves the five youngest half-tiles in flight and retires the one phase n+1
+// reads.  A phase is {LDS reads, DMA issue, counted wait | barrier | 16 MFMA | barrier}; wavefronts 4-7 run one
+// barrier behind wavefronts 0-3, so on every SIMD one wavefront issues MFMAs while the other one loads.
+// Ordering rules the schedule relies on: a slot is read one phase (or more) after the wait that retired its DMA,
+// with a barrier in between that every wavefront reaches after its own wait; a slot is re-filled two phases after
+// its last read, by which time both groups have passed the `lgkmcnt(0)` that follows that read.
+// Rows outside the image (zero padding) are fetched from a zero page; phases past the last K-tile fetch it too,
+// which keeps the wait count uniform.
+// ------------------------------------------------------------------------------------------------
+constexpr int PP_SLOT = 16384;
+constexpr int PP_TABLE = 8 * PP_SLOT;             // tap tables behind the ring (one LDS array for everything)
+constexpr int PP_LDS = PP_TABLE + 512;
+typedef TileCfg<256, 256, 2, 4> TilePipe;
+
+__device__ __attribute__((aligned(256))) unsigned char pp_zero_page[256];
+
+__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// ABL (timing experiments only, results are garbage): 1 = every DMA reads the zero page, 2 = no DMA at all,
+// 3 = no MFMA, 4 = no fragment reads
+template <typename TO, int ABL = 0>
+__global__ __launch_bounds__(512, 1) void conv_fwd_pipe_kernel(const ConvDev p) {
+  typedef TilePipe G;
+  constexpr int BKB = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* taps_l = reinterpret_cast<int*>(smem + PP_TABLE);           // [SEGK_MAX_SEG * 9]
+  int* ntaps_l = taps_l + SEGK_MAX_SEG * 9;                        // [SEGK_MAX_SEG]
+  unsigned int* mask_l = reinterpret_cast<unsigned int*>(ntaps_l + SEGK_MAX_SEG);  // [2]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nt = blockIdx.x % p.n_tiles;
+  const long long mt = blockIdx.x / p.n_tiles;
+  const int co0 = nt * G::BCO;
+  const long long m0 = mt * G::BPX;
+  const long long bz = blockIdx.y;
+
+  // ---- loader geometry: this thread's rows of every half-tile ------------------------------
+  // piece q = i*8 + wave (i = 0,1) covers half-tile rows q*8 .. q*8+7; lane l -> row q*8 + (l>>3), LDS slot l&7,
+  // which holds source chunk (l&7) ^ (row&7) (the XOR swizzle the fragment reads undo)
+  const int lrow = lane >> 3;
+  const int lchunk = ((lane & 7) ^ lrow) << 4;
+  int a_row[2][2], b_pix[2][2], b_y[2][2], b_x[2][2];
+  bool b_in[2][2];
 #pragma unroll
-  for (int j = 0; j < MJ; ++j) {
-    const long long m = m0 + wc * (MJ * 16) + j * 16 + fr;
-    if (m >= p.M) continue;
-    const long long n = m / p.HW;
-    char* orow = p.out + bz * p.out_batch_b + (size_t)m * p.out_ld * sizeof(TO);
+  for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int c = co0 + wr * (MI * 16) + i * 16 + fq * 4;
-      if (c >= cpad) continue;
-      float v[4];
+    for (int i = 0; i < 2; ++i) {
+      const int rr = (i * 8 + wave) * 8 + lrow;
+      a_row[h][i] = (rr >> 6) * 128 + h * 64 + (rr & 63);
+      b_pix[h][i] = (rr >> 5) * 64 + h * 32 + (rr & 31);
+      const long long m = m0 + b_pix[h][i];
+      b_in[h][i] = m < p.M;
+      const int rem = (int)((b_in[h][i] ? m : 0) % p.HW);
+      b_y[h][i] = rem / p.W;
+      b_x[h][i] = rem - b_y[h][i] * p.W;
+    }
+
+  // ---- which taps touch this tile at all -------------------------------------------------
+  if (tid < 2) mask_l[tid] = 0u;
+  __syncthreads();
+  {
+    unsigned long long mine = 0ull;
+    for (int sg = 0; sg < p.nseg; ++sg) {
+      const int R = p.seg[sg].R, dil = p.seg[sg].dil;
+      for (int tap = 0; tap < R * R; ++tap) {
+        const int dy = (tap / R - (R >> 1)) * dil, dx = (tap % R - (R >> 1)) * dil;
+        bool any = false;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float t = acc[i][j][r];
-        if (c + r < p.Cout) {
-          if (p.bias) t += p.bias[c + r];
-          if (p.img_bias) t += p.img_bias[n * p.Cout + c + r];
-        } else {
-          t = 0.f;
-        }
-        v[r] = t;
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            any |= b_in[h][i] && (unsigned)(b_y[h][i] + dy) < (unsigned)p.H && (unsigned)(b_x[h][i] + dx) < (unsigned)p.W;
+        if (any) mine |= 1ull << (sg * 9 + tap);
       }
-      store_out4<TO>(orow + (size_t)c * sizeof(TO), v);
+    }
+    const unsigned int lo = (unsigned int)mine, hi = (unsigned int)(mine >> 32);
+    if (lo) atomicOr(&mask_l[0], lo);
+    if (hi) atomicOr(&mask_l[1], hi);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned long long all = ((unsigned long long)mask_l[1] << 32) | mask_l[0];
+    for (int sg = 0; sg < p.nseg; ++sg) {
+      int cnt = 0;
+      const int R = p.seg[sg].R;
+      for (int tap = 0; tap < R * R; ++tap)
+        if ((all >> (sg * 9 + tap)) & 1ull) taps_l[sg * 9 + cnt++] = tap;
+      ntaps_l[sg] = cnt;
     }
   }
+  __syncthreads();
+  int total = 0;
+  for (int sg = 0; sg < p.nseg; ++sg) total += ntaps_l[sg] * (p.seg[sg].ck_b / BKB);
+
+  f32x4 acc[G::MI][G::MJ];
+#pragma unroll
+  for (int i = 0; i < G::MI; ++i)
+#pragma unroll
+    for (int j = 0; j < G::MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (total > 0) {
+    // ---- loader state: the K-tile whose half-tiles are being issued --------------------------
+    int l_tile = 0, l_sg = 0, l_ti = 0, l_kc = 0, l_nkc = 0, l_dy = 0, l_dx = 0;
+    while (ntaps_l[l_sg] == 0) ++l_sg;
+    unsigned aoff[2][2], boff[2][2];
+    const char* abase = nullptr;
+    const char* bbase = nullptr;
+    auto l_setup_seg = [&]() {
+      const SegDev& s = p.seg[l_sg];
+      l_nkc = s.ck_b / BKB;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          aoff[h][i] = (unsigned)a_row[h][i] * (unsigned)s.w_ld_b + lchunk;
+          boff[h][i] = (unsigned)b_pix[h][i] * (unsigned)s.in_ld_b + lchunk;
+        }
+    };
+    auto l_setup_tap = [&]() {
+      const SegDev& s = p.seg[l_sg];
+      const int tap = taps_l[l_sg * 9 + l_ti];
+      const int R = s.R;
+      l_dy = (tap / R - (R >> 1)) * s.dil;
+      l_dx = (tap % R - (R >> 1)) * s.dil;
+      abase = s.w + bz * s.w_batch_b + (long long)tap * s.w_tap_b + (long long)co0 * s.w_ld_b + (long long)l_kc * BKB;
+      bbase = s.in + bz * s.in_batch_b + (m0 + (long long)l_dy * p.W + l_dx) * s.in_ld_b + (long long)l_kc * BKB;
+    };
+    auto l_advance = [&]() {
+      if (++l_tile >= total) return;
+      if (++l_ti >= ntaps_l[l_sg]) {
+        l_ti = 0;
+        if (++l_kc >= l_nkc) {
+          l_kc = 0;
+          ++l_sg;
+          while (ntaps_l[l_sg] == 0) ++l_sg;
+          l_setup_seg();
+        }
+      }
+      l_setup_tap();
+    };
+    const char* zsrc = reinterpret_cast<const char*>(pp_zero_page) + ((lane & 7) << 4);
+    // issue this wavefront's two pieces of one half-tile: sub 0 = B0, 1 = A0, 2 = B1, 3 = A1 of the loader's K-tile
+    auto issue = [&](int sub, int slot) {
+      char* dst = smem + slot * PP_SLOT + wave * 1024;
+      if (ABL == 2) return;
+      const bool live = ABL == 1 ? false : l_tile < total;
+      const int h = sub >> 1;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const char* src;
+        if (sub & 1) {
+          src = live ? abase + aoff[h][i] : zsrc;
+        } else {
+          const bool ok = live && b_in[h][i] && (unsigned)(b_y[h][i] + l_dy) < (unsigned)p.H &&
+                          (unsigned)(b_x[h][i] + l_dx) < (unsigned)p.W;
+          src = ok ? bbase + boff[h][i] : zsrc;
+        }
+        glds16(src, dst + i * 8192);
+      }
+    };
+
+    // ---- fragment addressing ------------------------------------------------------------------
+    const int frow = lane & 15, fg = lane >> 4;
+    const int fsw = (fg ^ (frow & 7)) << 4;
+    const int fa_off = (wr * 64 + frow) * 128 + fsw;   // + i*2048, ^ (ks << 6)
+    const int fb_off = (wc * 32 + frow) * 128 + fsw;   // + j*2048, ^ (ks << 6)
+    u32x4 fa[4][2], fb1[2][2], fb0[2][2][2];
+
+    auto read_a = [&](int slot) {
+      if (ABL == 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(fa[i][ks]));
+        return;
+      }
+      const char* base = smem + slot * PP_SLOT;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          fa[i][ks] = *reinterpret_cast<const u32x4*>(base + ((fa_off + i * 2048) ^ (ks << 6)));
+    };
+    auto read_b = [&](int slot, u32x4 (&dst)[2][2]) {
+      if (ABL == 4) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(dst[j][ks]));
+        return;
+      }
+      const char* base = smem + slot * PP_SLOT;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          dst[j][ks] = *reinterpret_cast<const u32x4*>(base + ((fb_off + j * 2048) ^ (ks << 6)));
+    };
+    auto mma_quad = [&](int i0, int j0, const u32x4 (&b)[2][2]) {
+      if (ABL == 3) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[i][ks]));
+#pragma unroll
+          for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(b[j][ks]));
+        }
+        return;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) Mma<bf16_t>::run(fa[i][ks], b[j][ks], acc[i0 + i][j0 + j]);
+    };
+
+    // ---- prologue: half-tiles of data index -1 .. 5 (issue numbers 0 .. 6) -----------------------
+    l_setup_seg();
+    l_setup_tap();
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      issue(k & 3, (k + 7) & 7);
+      if ((k & 3) == 3) l_advance();
+    }
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // B0(0) and A0(0) have landed
+    __builtin_amdgcn_s_barrier();
+    read_b(7, fb0[0]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 1) __builtin_amdgcn_s_barrier();          // second group runs one barrier behind
+
+    // one phase; P = phase number modulo 8 (compile-time)
+#define SEGK_PHASE(P)                                                                          \
+  {                                                                                            \
+    if (((P) & 3) == 0) read_a((P) & 7);                                                       \
+    if (((P) & 3) == 1) read_b((P) & 7, fb1);                                                  \
+    if (((P) & 3) == 2) read_a((P) & 7);                                                       \
+    if (((P) & 3) == 3) read_b((P) & 7, fb0[1 - ((P) >> 2)]);                                  \
+    issue(((P) + 3) & 3, ((P) + 6) & 7);                                                       \
+    if (((P) & 3) == 0) l_advance();                                                           \
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    __builtin_amdgcn_s_barrier();                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                             \
+    if (((P) & 3) == 0) mma_quad(0, 0, fb0[(P) >> 2]);                                         \
+    if (((P) & 3) == 1) mma_quad(0, 2, fb1);                                                   \
+    if (((P) & 3) == 2) mma_quad(4, 2, fb1);                                                   \
+    if (((P) & 3) == 3) mma_quad(4, 0, fb0[(P) >> 2]);                                         \
+    __builtin_amdgcn_s_setprio(0);                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    __builtin_amdgcn_s_barrier();                                                              \
+  }
+    for (int t2 = 0; t2 < (total >> 1); ++t2) {
+      SEGK_PHASE(0) SEGK_PHASE(1) SEGK_PHASE(2) SEGK_PHASE(3)
+      SEGK_PHASE(4) SEGK_PHASE(5) SEGK_PHASE(6) SEGK_PHASE(7)
+    }
+    if (total & 1) {
+      SEGK_PHASE(0) SEGK_PHASE(1) SEGK_PHASE(2) SEGK_PHASE(3)
+    }
+#undef SEGK_PHASE
+    if (wr == 0) __builtin_amdgcn_s_barrier();          // pairs with the second group's last barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the dummy fetches of the last phases
+  }
+  __syncthreads();                                      // the epilogue reuses the ring for its reduction
+  conv_epilogue<TO, G>(p, acc, smem, wr, wc, lane, tid, co0, m0, mt, bz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -604,6 +903,30 @@ static int launch_fwd(ConvDev& d, hipStream_t st, int batch = 1) {
   return SEGK_OK;
 }
 
+template <typename TO, int ABL = 0>
+static int launch_pipe(ConvDev& d, hipStream_t st, int batch = 1) {
+  static bool configured = false;  // per instantiation
+  if (!configured) {
+    int rc = set_lds(conv_fwd_pipe_kernel<TO, ABL>, PP_LDS, "conv_fwd_pipe");
+    if (rc != SEGK_OK) return rc;
+    configured = true;
+  }
+  d.n_tiles = d.Cout / TilePipe::BCO;
+  const long long blocks = ((d.M + TilePipe::BPX - 1) / TilePipe::BPX) * d.n_tiles;
+  if (blocks >= 2147483647LL) {
+    set_error("conv: too many tiles");
+    return SEGK_INVALID_ARG;
+  }
+  conv_fwd_pipe_kernel<TO, ABL><<<dim3((unsigned)blocks, (unsigned)batch), 512, PP_LDS, st>>>(d);
+  return SEGK_OK;
+}
+
+// The deep-pipelined kernel replaces the big tile for bf16 operands (SEGK_CONV_PIPE=0 keeps the register-staged one).
+static bool use_pipe() {
+  static const char* e = getenv("SEGK_CONV_PIPE");
+  return !(e && e[0] == '0');
+}
+
 // Rows of statistic partials = pixel tiles of the geometry chosen for this problem.
 static bool use_big_tile(const ConvDev& d, bool wide) {
   // the big tile needs 128-byte K rows, full 256-channel tiles and enough tiles to fill 256 CUs twice
@@ -684,7 +1007,16 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
   const bool big = use_big_tile(d, wide);
   hipStream_t st = (hipStream_t)stream;
   static const char* abl = getenv("SEGK_CONV_ABL");
-  if (abl && big && a->dtype == SEGK_BF16 && a->out_dtype == SEGK_BF16) {
+  if (abl && abl[0] && big && use_pipe() && a->dtype == SEGK_BF16 && a->out_dtype == SEGK_BF16) {
+    rc = abl[0] == '1' ? launch_pipe<bf16_t, 1>(d, st)
+       : abl[0] == '2' ? launch_pipe<bf16_t, 2>(d, st)
+       : abl[0] == '3' ? launch_pipe<bf16_t, 3>(d, st)
+                       : launch_pipe<bf16_t, 4>(d, st);
+    if (rc != SEGK_OK) return rc;
+    SEGK_CHECK_LAUNCH("conv_fwd");
+    return SEGK_OK;
+  }
+  if (abl && abl[0] && big && a->dtype == SEGK_BF16 && a->out_dtype == SEGK_BF16) {
     rc = abl[0] == '1' ? launch_fwd<bf16_t, 128, bf16_t, TileBig, 1>(d, st)
        : abl[0] == '2' ? launch_fwd<bf16_t, 128, bf16_t, TileBig, 2>(d, st)
                        : launch_fwd<bf16_t, 128, bf16_t, TileBig, 3>(d, st);
@@ -695,7 +1027,9 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
 #define SEGK_LAUNCH(T, TO)                                                          \
   (big ? launch_fwd<T, 128, TO, TileBig>(d, st)                                     \
        : (wide ? launch_fwd<T, 128, TO, TileSmall>(d, st) : launch_fwd<T, 64, TO, TileSmall>(d, st)))
-  if (a->dtype == SEGK_BF16) {
+  if (a->dtype == SEGK_BF16 && big && use_pipe()) {
+    rc = a->out_dtype == SEGK_BF16 ? launch_pipe<bf16_t>(d, st) : launch_pipe<float>(d, st);
+  } else if (a->dtype == SEGK_BF16) {
     rc = a->out_dtype == SEGK_BF16 ? SEGK_LAUNCH(bf16_t, bf16_t) : SEGK_LAUNCH(bf16_t, float);
   } else {
     // fp32 rows of 32 channels are always 128 bytes
@@ -803,7 +1137,9 @@ extern "C" int segk_gemm_nt(const segk_gemm_args* a, segk_stream_t stream) {
 #define SEGK_LAUNCH(T, TO)                                                                   \
   (big ? launch_fwd<T, 128, TO, TileBig>(d, st, a->batch)                                    \
        : (wide ? launch_fwd<T, 128, TO, TileSmall>(d, st, a->batch) : launch_fwd<T, 64, TO, TileSmall>(d, st, a->batch)))
-  if (a->dtype == SEGK_BF16) {
+  if (a->dtype == SEGK_BF16 && big && use_pipe()) {
+    rc = a->c_dtype == SEGK_BF16 ? launch_pipe<bf16_t>(d, st, a->batch) : launch_pipe<float>(d, st, a->batch);
+  } else if (a->dtype == SEGK_BF16) {
     rc = a->c_dtype == SEGK_BF16 ? SEGK_LAUNCH(bf16_t, bf16_t) : SEGK_LAUNCH(bf16_t, float);
   } else {
     rc = a->c_dtype == SEGK_BF16
