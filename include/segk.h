@@ -248,7 +248,10 @@ int segk_upsample_fwd(const void* in, int in_dtype, int in_ld, int N, int C, int
  * C..din_cpad of din are written as zero. */
 int segk_upsample_bwd(const void* dout, int dout_dtype, int dout_layout, int dout_ld, int N, int C, int Ho,
                       int Wo, void* din, int din_dtype, int din_ld, int din_cpad, int Hi, int Wi,
-                      segk_stream_t stream);
+                      float* workspace, segk_stream_t stream);
+/* fp32 elements of `workspace` that let the NCHW form run as two separable passes (rows, then columns) instead
+ * of one gather kernel; 0 for the pixel-major form.  workspace may be NULL (the gather kernel is used). */
+long long segk_upsample_bwd_workspace(int dout_layout, int N, int C, int Ho, int Wi);
 
 /* ---- loss ----------------------------------------------------------------------------------- */
 /* nn.CrossEntropyLoss(weight, ignore_index) on NCHW fp32 logits and fp32 label maps (utils/loss.py:23-35).

@@ -417,7 +417,9 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
 }
 
 // ABL (timing experiments only, results are garbage): 1 = every DMA reads the zero page, 2 = no DMA at all,
-// 3 = no MFMA, 4 = no fragment reads
+// 3 = no MFMA, 4 = no fragment reads, 6 = no DMA and no fragment reads (MFMA + barriers only),
+// 7 = no main loop, 9 = s_memtime stamps per phase section, summed per wavefront into the statistics buffer,
+// 8 = every workgroup fetches the pixels of tile 0 (real addressing, cache-resident data)
 template <typename TO, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void conv_fwd_pipe_kernel(const ConvDev p) {
   typedef TilePipe G;
@@ -493,6 +495,7 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_pipe_kernel(const ConvDev p) 
   __syncthreads();
   int total = 0;
   for (int sg = 0; sg < p.nseg; ++sg) total += ntaps_l[sg] * (p.seg[sg].ck_b / BKB);
+  if (ABL == 7) total = 0;  // prologue + epilogue only
 
   f32x4 acc[G::MI][G::MJ];
 #pragma unroll
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_pipe_kernel(const ConvDev p) 
       l_dy = (tap / R - (R >> 1)) * s.dil;
       l_dx = (tap % R - (R >> 1)) * s.dil;
       abase = s.w + bz * s.w_batch_b + (long long)tap * s.w_tap_b + (long long)co0 * s.w_ld_b + (long long)l_kc * BKB;
-      bbase = s.in + bz * s.in_batch_b + (m0 + (long long)l_dy * p.W + l_dx) * s.in_ld_b + (long long)l_kc * BKB;
+      bbase = s.in + bz * s.in_batch_b + ((ABL == 8 ? 1024 : m0) + (long long)l_dy * p.W + l_dx) * s.in_ld_b + (long long)l_kc * BKB;
     };
     auto l_advance = [&]() {
       if (++l_tile >= total) return;
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_pipe_kernel(const ConvDev p) 
     // issue this wavefront's two pieces of one half-tile: sub 0 = B0, 1 = A0, 2 = B1, 3 = A1 of the loader's K-tile
     auto issue = [&](int sub, int slot) {
       char* dst = smem + slot * PP_SLOT + wave * 1024;
-      if (ABL == 2) return;
+      if (ABL == 2 || ABL == 6) return;
       const bool live = ABL == 1 ? false : l_tile < total;
       const int h = sub >> 1;
 #pragma unroll
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_pipe_kernel(const ConvDev p) 
     u32x4 fa[4][2], fb1[2][2], fb0[2][2][2];
 
     auto read_a = [&](int slot) {
-      if (ABL == 4) {
+      if (ABL == 4 || ABL == 6) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -584,7 +587,7 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_pipe_kernel(const ConvDev p) 
           fa[i][ks] = *reinterpret_cast<const u32x4*>(base + ((fa_off + i * 2048) ^ (ks << 6)));
     };
     auto read_b = [&](int slot, u32x4 (&dst)[2][2]) {
-      if (ABL == 4) {
+      if (ABL == 4 || ABL == 6) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -632,20 +635,33 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_pipe_kernel(const ConvDev p) 
     __builtin_amdgcn_sched_barrier(0);
     if (wr == 1) __builtin_amdgcn_s_barrier();          // second group runs one barrier behind
 
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int k) {
+      if (ABL != 9) return;
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      if (k >= 0) tacc[k] += now - tprev;
+      tprev = now;
+    };
+    stamp(-1);
     // one phase; P = phase number modulo 8 (compile-time)
 #define SEGK_PHASE(P)                                                                          \
   {                                                                                            \
+    stamp(5);                                                                                  \
     if (((P) & 3) == 0) read_a((P) & 7);                                                       \
     if (((P) & 3) == 1) read_b((P) & 7, fb1);                                                  \
     if (((P) & 3) == 2) read_a((P) & 7);                                                       \
     if (((P) & 3) == 3) read_b((P) & 7, fb0[1 - ((P) >> 2)]);                                  \
     issue(((P) + 3) & 3, ((P) + 6) & 7);                                                       \
     if (((P) & 3) == 0) l_advance();                                                           \
+    stamp(0);                                                                                  \
     asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                          \
     __builtin_amdgcn_sched_barrier(0);                                                         \
+    stamp(1);                                                                                  \
     __builtin_amdgcn_s_barrier();                                                              \
+    stamp(2);                                                                                  \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
     __builtin_amdgcn_sched_barrier(0);                                                         \
+    stamp(3);                                                                                  \
     __builtin_amdgcn_s_setprio(1);                                                             \
     if (((P) & 3) == 0) mma_quad(0, 0, fb0[(P) >> 2]);                                         \
     if (((P) & 3) == 1) mma_quad(0, 2, fb1);                                                   \
@@ -653,6 +669,7 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_pipe_kernel(const ConvDev p) 
     if (((P) & 3) == 3) mma_quad(4, 0, fb0[(P) >> 2]);                                         \
     __builtin_amdgcn_s_setprio(0);                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                         \
+    stamp(4);                                                                                  \
     __builtin_amdgcn_s_barrier();                                                              \
   }
     for (int t2 = 0; t2 < (total >> 1); ++t2) {
@@ -665,8 +682,14 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_pipe_kernel(const ConvDev p) 
 #undef SEGK_PHASE
     if (wr == 0) __builtin_amdgcn_s_barrier();          // pairs with the second group's last barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the dummy fetches of the last phases
+    if (ABL == 9 && p.stat && lane == 0) {
+      // [tile][wave][6] sums of cycles: load section, vmcnt wait, barrier 1, lgkmcnt wait, MFMA section, barrier 2
+      for (int k = 0; k < 6; ++k) p.stat[((size_t)mt * 2) * p.Cout + wave * 8 + k] = (double)tacc[k];
+      p.stat[((size_t)mt * 2) * p.Cout + wave * 8 + 6] = (double)total;
+    }
   }
   __syncthreads();                                      // the epilogue reuses the ring for its reduction
+  if (ABL == 9) return;
   conv_epilogue<TO, G>(p, acc, smem, wr, wc, lane, tid, co0, m0, mt, bz);
 }
 
@@ -921,10 +944,12 @@ static int launch_pipe(ConvDev& d, hipStream_t st, int batch = 1) {
   return SEGK_OK;
 }
 
-// The deep-pipelined kernel replaces the big tile for bf16 operands (SEGK_CONV_PIPE=0 keeps the register-staged one).
+// The deep-pipelined kernel is opt-in (SEGK_CONV_PIPE=1): measured on the decoder's 3x3 convolutions it ties the
+// register-staged big tile, because both are bound by the rate at which a CU can pull operand tiles through its
+// vector L1 (about 20 bytes per cycle), not by staging registers or by the barrier structure.
 static bool use_pipe() {
   static const char* e = getenv("SEGK_CONV_PIPE");
-  return !(e && e[0] == '0');
+  return e && e[0] == '1';
 }
 
 // Rows of statistic partials = pixel tiles of the geometry chosen for this problem.
@@ -1011,6 +1036,10 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
     rc = abl[0] == '1' ? launch_pipe<bf16_t, 1>(d, st)
        : abl[0] == '2' ? launch_pipe<bf16_t, 2>(d, st)
        : abl[0] == '3' ? launch_pipe<bf16_t, 3>(d, st)
+       : abl[0] == '6' ? launch_pipe<bf16_t, 6>(d, st)
+       : abl[0] == '7' ? launch_pipe<bf16_t, 7>(d, st)
+       : abl[0] == '8' ? launch_pipe<bf16_t, 8>(d, st)
+       : abl[0] == '9' ? launch_pipe<bf16_t, 9>(d, st)
                        : launch_pipe<bf16_t, 4>(d, st);
     if (rc != SEGK_OK) return rc;
     SEGK_CHECK_LAUNCH("conv_fwd");

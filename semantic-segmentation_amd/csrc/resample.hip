@@ -227,89 +227,64 @@ __global__ __launch_bounds__(256) void upsample_bwd_nchw_kernel(const float* __r
   Elem<TG>::store(din + (((size_t)n * Hi + iy) * Wi + ix) * din_ld + c, acc);
 }
 
-// Tiled form of the NCHW gradient for up-sampling ratios up to ~4.5x: a block owns a 16x16 tile of input
-// pixels of one image and walks up to 32 channels.  Per channel the output-gradient window that feeds the
-// tile (<= 76x76) is staged in LDS with coalesced row reads, every thread accumulates its <= 12x12 window
-// with weights precomputed once per tile row/column, and the per-pixel channel vectors leave through LDS so
-// the pixel-major store is contiguous.  HBM traffic ~= 1.1x the gradient tensor, read once.
-constexpr int UB_TI = 16, UB_MAXR = 76, UB_MAXK = 12, UB_CCH = 32;
+// Separable form of the NCHW gradient (any ratio), two passes through an fp32 workspace [N][C][Ho][Wi]:
+//   rows:  ws[n][c][oy][ix] = sum_ox wx(ox, ix) * dout[n][c][oy][ox]     reads the gradient once, coalesced
+//   cols:  din[n][iy][ix][c] = sum_oy wy(oy, iy) * ws[n][c][oy][ix]      reads the (Wo/Wi times smaller) workspace
+// HBM traffic = gradient + 2 x workspace + result, against ~9 x slower gather kernels that re-read through L2.
+constexpr int UR_ROWS = 4;   // gradient rows per workgroup of the row pass
 
-template <typename TG>
-__global__ __launch_bounds__(256) void upsample_bwd_nchw_tiled_kernel(const float* __restrict__ dout, int C, int Ho,
-                                                                       int Wo, TG* __restrict__ din, int din_ld, int cpad,
-                                                                       int Hi, int Wi, float sy, float sx, int tiles_x) {
-  __shared__ float tile[UB_MAXR][UB_MAXR + 1];
-  __shared__ float wys[UB_TI][UB_MAXK], wxs[UB_TI][UB_MAXK];
-  __shared__ int y0s[UB_TI], x0s[UB_TI];
-  __shared__ float outs[256][UB_CCH + 1];
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const int n = blockIdx.y, c0 = blockIdx.z * UB_CCH;
-  const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-  int ylo, yhi, xlo, xhi, tmp;
-  reader_range(ty * UB_TI, sy, Ho, ylo, tmp);
-  reader_range(min(ty * UB_TI + UB_TI - 1, Hi - 1), sy, Ho, tmp, yhi);
-  reader_range(tx * UB_TI, sx, Wo, xlo, tmp);
-  reader_range(min(tx * UB_TI + UB_TI - 1, Wi - 1), sx, Wo, tmp, xhi);
-  const int ry = yhi - ylo + 1, rx = xhi - xlo + 1;
-  // weights of the tile's rows and columns (threads 0..15: rows, 16..31: columns)
-  if (threadIdx.x < 2 * UB_TI) {
-    const bool isrow = threadIdx.x < UB_TI;
-    const int l = threadIdx.x & (UB_TI - 1);
-    const int i = (isrow ? ty : tx) * UB_TI + l;
-    const int in_size = isrow ? Hi : Wi, out_size = isrow ? Ho : Wo;
-    const float sc = isrow ? sy : sx;
-    int lo = 0, hi = -1;
-    if (i < in_size) reader_range(i, sc, out_size, lo, hi);
-    for (int k = 0; k < UB_MAXK; ++k) {
-      const int o = lo + k;
-      const float w = (o <= hi) ? tap_weight(o, i, sc, in_size) : 0.f;
-      if (isrow) wys[l][k] = w; else wxs[l][k] = w;
-    }
-    if (isrow) y0s[l] = lo - ylo; else x0s[l] = lo - xlo;
-  }
+__global__ __launch_bounds__(256) void upsample_bwd_rows_kernel(const float* __restrict__ dout, long long rows, int Wo,
+                                                                int Wi, float sx, float* __restrict__ ws) {
+  extern __shared__ float rowbuf[];  // [UR_ROWS][Wo]
+  const long long r0 = (long long)blockIdx.x * UR_ROWS;
+  const int nr = (int)(rows - r0 < UR_ROWS ? rows - r0 : UR_ROWS);
+  const float* src = dout + r0 * Wo;
+  for (int i = threadIdx.x; i < nr * Wo; i += 256) rowbuf[i] = src[i];
   __syncthreads();
-  const int oy0 = y0s[ly], ox0 = x0s[lx];
-  const int nch = min(UB_CCH, cpad - c0);
-  for (int c = 0; c < nch; ++c) {
+  for (int idx = threadIdx.x; idx < nr * Wi; idx += 256) {
+    const int r = idx / Wi, ix = idx - r * Wi;
+    int lo, hi;
+    reader_range(ix, sx, Wo, lo, hi);
+    const float* row = rowbuf + r * Wo;
     float a = 0.f;
-    if (c0 + c < C) {
-      const float* src = dout + (((size_t)n * C + c0 + c) * Ho + ylo) * Wo + xlo;
-      for (int idx = threadIdx.x; idx < ry * rx; idx += 256) {
-        const int oy = idx / rx, ox = idx - oy * rx;
-        tile[oy][ox] = src[(size_t)oy * Wo + ox];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int ky = 0; ky < UB_MAXK; ++ky) {
-        const float wy = wys[ly][ky];
-        if (wy != 0.f) {
-          float r = 0.f;
-#pragma unroll
-          for (int kx = 0; kx < UB_MAXK; ++kx) {
-            const float wx = wxs[lx][kx];
-            if (wx != 0.f) r = fmaf(wx, tile[oy0 + ky][ox0 + kx], r);
-          }
-          a = fmaf(wy, r, a);
-        }
-      }
-      __syncthreads();
+    for (int ox = lo; ox <= hi; ++ox) {
+      const float w = tap_weight(ox, ix, sx, Wi);
+      if (w != 0.f) a = fmaf(w, row[ox], a);
     }
-    outs[threadIdx.x][c] = a;
-  }
-  __syncthreads();
-  // store: consecutive threads take consecutive channels of one pixel
-  for (int idx = threadIdx.x; idx < 256 * nch; idx += 256) {
-    const int p = idx / nch, c = idx - p * nch;
-    const int py = ty * UB_TI + (p >> 4), px = tx * UB_TI + (p & 15);
-    if (py < Hi && px < Wi) Elem<TG>::store(din + (((size_t)n * Hi + py) * Wi + px) * din_ld + c0 + c, outs[p][c]);
+    ws[(r0 + r) * Wi + ix] = a;
   }
 }
 
-// can the tiled kernel hold this ratio's windows?
-static bool tiled_bwd_fits(float scale) {
-  if (scale <= 0.f) return false;
-  const float inv = 1.f / scale;
-  return (2.f * inv + 4.f) <= (float)UB_MAXK && ((UB_TI + 1) * inv + 5.f) <= (float)UB_MAXR;
+constexpr int UC_PIX = 64, UC_CH = 32;
+
+template <typename TG>
+__global__ __launch_bounds__(256) void upsample_bwd_cols_kernel(const float* __restrict__ ws, int C, int Ho, int Hi, int Wi,
+                                                                float sy, TG* __restrict__ din, int din_ld, int cpad) {
+  __shared__ float outs[UC_PIX][UC_CH + 1];
+  const int x0 = blockIdx.x * UC_PIX, iy = blockIdx.y % Hi, n = blockIdx.y / Hi, c0 = blockIdx.z * UC_CH;
+  const int lx = threadIdx.x & (UC_PIX - 1), cg = threadIdx.x / UC_PIX;   // 4 channel groups of 8
+  int lo, hi;
+  reader_range(iy, sy, Ho, lo, hi);
+  const int ix = x0 + lx;
+#pragma unroll
+  for (int k = 0; k < UC_CH / 4; ++k) {
+    const int cl = cg * (UC_CH / 4) + k, c = c0 + cl;
+    float a = 0.f;
+    if (c < C && ix < Wi) {
+      const float* col = ws + (((size_t)n * C + c) * Ho) * Wi + ix;
+      for (int oy = lo; oy <= hi; ++oy) {
+        const float w = tap_weight(oy, iy, sy, Hi);
+        if (w != 0.f) a = fmaf(w, col[(size_t)oy * Wi], a);
+      }
+    }
+    outs[lx][cl] = a;
+  }
+  __syncthreads();
+  const int nch = min(UC_CH, cpad - c0);
+  for (int idx = threadIdx.x; idx < UC_PIX * nch; idx += 256) {
+    const int p = idx / nch, c = idx - p * nch;
+    if (x0 + p < Wi) Elem<TG>::store(din + (((size_t)n * Hi + iy) * Wi + x0 + p) * din_ld + c0 + c, outs[p][c]);
+  }
 }
 
 static bool aligned_to(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
@@ -367,9 +342,14 @@ extern "C" int segk_upsample_fwd(const void* in, int in_dtype, int in_ld, int N,
   return SEGK_OK;
 }
 
+extern "C" long long segk_upsample_bwd_workspace(int dout_layout, int N, int C, int Ho, int Wi) {
+  if (dout_layout != SEGK_NCHW || N <= 0 || C <= 0 || Ho <= 0 || Wi <= 0) return 0;
+  return (long long)N * C * Ho * Wi;
+}
+
 extern "C" int segk_upsample_bwd(const void* dout, int dout_dtype, int dout_layout, int dout_ld, int N, int C, int Ho,
                                  int Wo, void* din, int din_dtype, int din_ld, int din_cpad, int Hi, int Wi,
-                                 segk_stream_t stream) {
+                                 float* workspace, segk_stream_t stream) {
   SEGK_REQUIRE(dout && din && valid_dtype(dout_dtype) && valid_dtype(din_dtype), "upsample_bwd: null pointer or bad dtype");
   SEGK_REQUIRE(N > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && din_cpad >= C && din_ld >= din_cpad,
                "upsample_bwd: bad shape C=%d cpad=%d ld=%d", C, din_cpad, din_ld);
@@ -388,12 +368,15 @@ extern "C" int segk_upsample_bwd(const void* dout, int dout_dtype, int dout_layo
                                                                                din_ld, din_cpad, Hi, Wi, sy, sx, total)));
   } else if (dout_layout == SEGK_NCHW) {
     SEGK_REQUIRE(dout_dtype == SEGK_F32, "upsample_bwd: the NCHW gradient is fp32");
-    if (tiled_bwd_fits(sy) && tiled_bwd_fits(sx) && N <= 65535 && ceil_div(din_cpad, UB_CCH) <= 65535) {
-      const int tiles_x = ceil_div(Wi, UB_TI), tiles_y = ceil_div(Hi, UB_TI);
-      dim3 grid(tiles_x * tiles_y, N, ceil_div(din_cpad, UB_CCH));
-      SEGK_DISPATCH_DTYPE(din_dtype, T, (upsample_bwd_nchw_tiled_kernel<T><<<grid, 256, 0, st>>>(
-                                            (const float*)dout, C, Ho, Wo, (T*)din, din_ld, din_cpad, Hi, Wi, sy, sx,
-                                            tiles_x)));
+    const long long rows = (long long)N * C * Ho;
+    if (workspace && (long long)Wo * UR_ROWS * 4 <= 65536 && ceil_div(rows, UR_ROWS) < 2147483647LL &&
+        (long long)N * Hi <= 65535 && ceil_div(din_cpad, UC_CH) <= 65535) {
+      upsample_bwd_rows_kernel<<<ceil_div(rows, UR_ROWS), 256, (size_t)UR_ROWS * Wo * sizeof(float), st>>>(
+          (const float*)dout, rows, Wo, Wi, sx, workspace);
+      SEGK_CHECK_LAUNCH("upsample_bwd rows");
+      dim3 grid(ceil_div(Wi, UC_PIX), N * Hi, ceil_div(din_cpad, UC_CH));
+      SEGK_DISPATCH_DTYPE(din_dtype, T, (upsample_bwd_cols_kernel<T><<<grid, 256, 0, st>>>(workspace, C, Ho, Hi, Wi, sy, (T*)din,
+                                                                                         din_ld, din_cpad)));
     } else {
       SEGK_REQUIRE((long long)N * din_cpad <= 65535 && ceil_div(Hi, 4) <= 65535, "upsample_bwd: grid too large");
       dim3 grid(ceil_div(Wi, 64), ceil_div(Hi, 4), N * din_cpad);

@@ -90,7 +90,8 @@ SIGNATURES = {
     "segk_upsample_fwd": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
                           c_int, c_void_p],
     "segk_upsample_bwd": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int,
-                          c_int, c_int, c_void_p],
+                          c_int, c_int, c_void_p, c_void_p],
+    "segk_upsample_bwd_workspace": [c_int, c_int, c_int, c_int, c_int],
     "segk_ce_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                     c_void_p],
     "segk_ce_partial_rows": [c_ll],
@@ -99,7 +100,7 @@ SIGNATURES = {
     "segk_argmax": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "segk_confmat": [c_void_p, c_int, c_void_p, c_ll, c_int, c_void_p, c_void_p],
 }
-_RESTYPES = {"segk_last_error": ctypes.c_char_p}
+_RESTYPES = {"segk_last_error": ctypes.c_char_p, "segk_upsample_bwd_workspace": c_ll}
 
 _lib = None
 

@@ -458,7 +458,7 @@ class SyncBNFunction(torch.autograd.Function):
     """Stand-alone batch norm on NCHW (or channels_last) tensors: the feeder's layers."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, mod):
+    def forward(ctx, x, gamma, beta, mod, relu=False):
         spec = _BNSpec(mod)
         layout, xv, shape = NCHW, x, x.shape
         v = pm_view_of(x) if x.dim() == 4 else None
@@ -480,17 +480,17 @@ class SyncBNFunction(torch.autograd.Function):
             coef = ops.bn_coeffs_eval(spec.running_mean, spec.running_var, gamma, beta, spec.eps)
         if layout == PM:
             y = torch.empty_like(x, memory_format=torch.channels_last)
-            ops.bn_apply(xv, pm_view_of(y), coef, PM, False)
+            ops.bn_apply(xv, pm_view_of(y), coef, PM, relu)
         else:
             y = torch.empty_like(xv)
-            ops.bn_apply(xv, y, coef, NCHW, False)
-        ctx.saved = (xv, coef, layout, spec.training, spec.sync, x.dtype, shape)
+            ops.bn_apply(xv, y, coef, NCHW, relu)
+        ctx.saved = (xv, coef, layout, spec.training, spec.sync, x.dtype, shape, relu)
         ctx.affine = gamma is not None
         return y if y.dtype == x.dtype else y.to(x.dtype)
 
     @staticmethod
     def backward(ctx, g):
-        xv, coef, layout, training, sync, in_dtype, shape = ctx.saved
+        xv, coef, layout, training, sync, in_dtype, shape, relu = ctx.saved
         C = shape[1]
         if layout == PM:
             gv = pm_view_of(g)
@@ -503,15 +503,16 @@ class SyncBNFunction(torch.autograd.Function):
             gv = g.to(xv.dtype).contiguous()
             dx = torch.empty_like(xv)
             dxv = dx
-        local = ops.bn_bwd_local_sums(gv, xv, coef, layout, False)
+        # the ReLU pattern is recomputed from x*scale + shift, so the fused form keeps no extra tensor
+        local = ops.bn_bwd_local_sums(gv, xv, coef, layout, relu)
         dbeta, dgamma = local[:C].float(), local[C:2 * C].float()
         gs = _global_sums(local, sync and training)
-        ops.bn_bwd_apply(gv, xv, dxv, coef, gs, layout, False, eval_mode=not training)
+        ops.bn_bwd_apply(gv, xv, dxv, coef, gs, layout, relu, eval_mode=not training)
         if dx.dtype != in_dtype:
             dx = dx.to(in_dtype)
         if not ctx.affine:
             dgamma = dbeta = None
-        return dx, dgamma, dbeta, None
+        return dx, dgamma, dbeta, None, None
 
 
 # ------------------------------------------------------------ plain conv ----

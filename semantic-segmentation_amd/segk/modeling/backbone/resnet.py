@@ -19,6 +19,12 @@ import torch.nn as nn
 _MULTI_GRID = (1, 2, 4)
 
 
+def _bn_relu(bn, relu, x):
+    """relu(bn(x)); batch-norm classes that offer a fused form (`forward_relu`) do it in one pass."""
+    fused = getattr(bn, "forward_relu", None)
+    return fused(x) if fused is not None else relu(bn(x))
+
+
 def _conv(cin, cout, k, stride=1, dilation=1):
     pad = dilation if k == 3 else (3 if k == 7 else 0)
     return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=pad, dilation=dilation, bias=False)
@@ -41,8 +47,8 @@ class Bottleneck(nn.Module):
         self.dilation = dilation
 
     def forward(self, x):
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.relu(self.bn2(self.conv2(y)))
+        y = _bn_relu(self.bn1, self.relu, self.conv1(x))
+        y = _bn_relu(self.bn2, self.relu, self.conv2(y))
         y = self.bn3(self.conv3(y))
         # the projection runs after the main path: autograd then sums the gradients that
         # reach x in the same order as the reference does, which keeps training bit-identical
@@ -88,7 +94,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*blocks)
 
     def forward(self, input):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(input))))
+        x = self.maxpool(_bn_relu(self.bn1, self.relu, self.conv1(input)))
         low_level_feat = self.layer1(x)
         x = self.layer4(self.layer3(self.layer2(low_level_feat)))
         return x, low_level_feat

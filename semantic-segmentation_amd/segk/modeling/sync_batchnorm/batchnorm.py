@@ -25,6 +25,14 @@ class _SynchronizedBatchNorm(_BatchNorm):
             raise ValueError("expected %d channels, got %d" % (self.num_features, input.shape[1]))
         return SF.SyncBNFunction.apply(input, self.weight, self.bias, self)
 
+    def forward_relu(self, input):
+        """relu(self(input)) in one pass (and one pass fewer in backward): for callers that apply a ReLU right
+        behind this layer, as every feeder block does (modeling/backbone/resnet101.py Bottleneck.forward)."""
+        self._check_input_dim(input)
+        if input.shape[1] != self.num_features:
+            raise ValueError("expected %d channels, got %d" % (self.num_features, input.shape[1]))
+        return SF.SyncBNFunction.apply(input, self.weight, self.bias, self, True)
+
     def __data_parallel_replicate__(self, ctx, copy_id):
         raise RuntimeError("this SynchronizedBatchNorm runs one process per GPU (torch.distributed); "
                            "nn.DataParallel replication is not supported")

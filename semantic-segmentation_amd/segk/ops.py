@@ -507,8 +507,10 @@ def upsample_bwd(dout, dout_layout, N, C, Ho, Wo, din, cpad, Hi, Wi):
     if dout_layout == NCHW and not dout.is_contiguous():
         raise ValueError("NCHW gradient must be contiguous")
     din_ld = _pm(din)[0]
+    n_ws = call("segk_upsample_bwd_workspace", dout_layout, N, C, Ho, Wi)
+    ws = torch.empty((n_ws,), dtype=torch.float32, device=dout.device) if n_ws > 0 else None
     call("segk_upsample_bwd", _ptr(dout), _dt(dout), dout_layout, dout_ld, N, C, Ho, Wo, _ptr(din), _dt(din), din_ld,
-         cpad, Hi, Wi, _stream())
+         cpad, Hi, Wi, _ptr(ws), _stream())
     return din
 
 
