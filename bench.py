@@ -99,6 +99,22 @@ def cpu_baseline(args):
                       % (args.out_stride, args.classes, args.cpu_batch, args.size, args.size, sec)}
 
 
+def measured_traffic(args, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes (tools/pmc_traffic.sh: one
+    FETCH_SIZE pass and one WRITE_SIZE pass over this same bench command, FETCH_SIZE doubled as gfx950 requires).
+    Counters cannot be collected from inside a timed run, so the figure is read from profiles/; it applies to
+    the default workload only."""
+    default = (args.batch, args.size, args.classes, args.out_stride, args.dtype) == (16, 513, 21, 16, "bf16")
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not default or not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            return float(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"])
+    except (KeyError, ValueError, OSError):
+        return None
+
+
 def main():
     args = parse()
     from segk import config, ops, parallel
@@ -194,7 +210,10 @@ def main():
                 peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MATRIX_PEAK_TFLOPS
                 ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
                 line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                                    "frac": ach / peak, "traffic": None, "kernel": "conv_fwd_kernel (implicit-GEMM "
+                                    "frac": ach / peak, "traffic": measured_traffic(args, "conv_fwd_kernel"),
+                                    "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
+                                                    "profiles/pmc_traffic.json)",
+                                    "kernel": "conv_fwd_kernel (implicit-GEMM "
                                     "forward + data gradient, all %d launches of the timed steps)" % dom["launches"],
                                     "avg_launch_ms": dom["avg_ms"],
                                     "share_of_step": dom["ms"] / (1000.0 * elapsed)}

@@ -775,25 +775,34 @@ struct WgFrag<float> {
   }
 };
 
-template <typename T>
-__global__ __launch_bounds__(CONV_THREADS, 2) void conv_wgrad_kernel(const WgradDev p) {
+// NSUB = 1: 128(co) x 128(ci) tile, 4 wavefronts of 64 x 64, two workgroups per CU.
+// NSUB = 2: 256 x 256 tile (each operand tile = two 128-channel sub-tiles side by side), 8 wavefronts of
+//           128(co) x 64(ci), one workgroup per CU: twice the MFMA work per byte that crosses the vector L1.
+template <typename T, int NSUB>
+__global__ __launch_bounds__(CONV_THREADS * NSUB, NSUB == 1 ? 2 : 1) void conv_wgrad_kernel(const WgradDev p) {
+  constexpr int NT = CONV_THREADS * NSUB;
+  constexpr int TCH = TILE * NSUB;               // channels per operand tile
   constexpr int BP = WgFrag<T>::BP;
-  constexpr int RB = TILE * (int)sizeof(T);      // tile row bytes
-  constexpr int CH = RB / 16;                    // 16-byte chunks per row (16 bf16 / 32 fp32)
-  constexpr int RPP = CONV_THREADS / CH;         // rows per pass
-  constexpr int NP = BP / RPP;                   // passes (4 for both dtypes)
-  constexpr int TILE_B = BP * RB;                // 16 KB
+  constexpr int RB = TILE * (int)sizeof(T);      // sub-tile row bytes
+  constexpr int CHS = RB / 16;                   // 16-byte chunks per sub-tile row (16 bf16 / 32 fp32)
+  constexpr int CH = CHS * NSUB;                 // chunks per operand-tile row
+  constexpr int RPP = NT / CH;                   // rows per pass
+  constexpr int NP = BP / RPP;                   // passes (4 in every variant)
+  constexpr int SUB_B = BP * RB;                 // 16 KB per sub-tile
+  constexpr int TILE_B = SUB_B * NSUB;
+  constexpr int MI = 4 * NSUB, MJ = 4;           // MFMA tiles per wavefront: co x ci
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][dout tile | in tile]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = NSUB == 1 ? wave >> 1 : wave >> 2;   // co block of MI*16 channels
+  const int wc = NSUB == 1 ? wave & 1 : wave & 3;     // ci block of 64 channels
   int b = blockIdx.x;
   const int cot = b % p.co_tiles; b /= p.co_tiles;
   const int cit = b % p.ci_tiles; b /= p.ci_tiles;
   const int taps = p.R * p.R;
   const int tap = b % taps;
   const int sp = b / taps;
-  const int co0 = cot * TILE, ci0 = cit * TILE;
+  const int co0 = cot * TCH, ci0 = cit * TCH;
   const int dy = (tap / p.R - (p.R >> 1)) * p.dil, dx = (tap % p.R - (p.R >> 1)) * p.dil;
   const long long pbeg = (long long)sp * p.per_split;
   long long pend = pbeg + p.per_split;
@@ -801,6 +810,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_wgrad_kernel(const Wgrad
   const int nchunks = pbeg < pend ? (int)((pend - pbeg + BP - 1) / BP) : 0;
 
   const int lc = tid % CH, lr = tid / CH;
+  const int lsub = lc / CHS, lcs = lc % CHS;     // sub-tile and chunk within it
   const int esz = (int)sizeof(T);
   const int ch_per_chunk = 16 / esz;
   const bool d_ok = co0 + lc * ch_per_chunk < p.Cout;  // Cout, Cin are multiples of 16 / 32 elements
@@ -809,12 +819,14 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_wgrad_kernel(const Wgrad
   const char* dbase = p.dout + bz * p.dout_batch_b + (size_t)(co0 + lc * ch_per_chunk) * esz;
   const char* xbase = p.in + bz * p.in_batch_b + (size_t)(ci0 + lc * ch_per_chunk) * esz;
 
-  f32x4 acc[4][4];
+  f32x4 acc[MI][MJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // wavefronts whose input or output channels lie entirely beyond the tensor (partial last tile) skip the MFMA work
+  const bool wave_live = ci0 + wc * 64 < p.Cin && co0 + wr * (MI * 16) < p.Cout;
   u32x4 rd[NP], rx[NP];
   // load chunk `ck`; returns whether any of this thread's shifted rows is inside the image
   auto load_chunk = [&](int ck) -> int {
@@ -839,11 +851,11 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_wgrad_kernel(const Wgrad
     return any;
   };
   auto store_chunk = [&](int stage) {
-    char* sd = smem + stage * 2 * TILE_B;
+    char* sd = smem + stage * 2 * TILE_B + lsub * SUB_B;
     char* sx = sd + TILE_B;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const int off = wg_chunk_off<T>(lr + i * RPP, lc);
+      const int off = wg_chunk_off<T>(lr + i * RPP, lcs);
       *reinterpret_cast<u32x4*>(sd + off) = rd[i];
       *reinterpret_cast<u32x4*>(sx + off) = rx[i];
     }
@@ -858,20 +870,23 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_wgrad_kernel(const Wgrad
       const bool more = ck + 1 < nchunks;
       any = 0;
       if (more) any = load_chunk(ck + 1);
-      if (cur_any) {
-        const char* sd = smem + cur * 2 * TILE_B;
-        const char* sx = sd + TILE_B;
+      if (cur_any && wave_live) {
+        // this wavefront's co channels lie in one sub-tile (NSUB = 2: wr selects it), its ci channels too
+        const char* sd = smem + cur * 2 * TILE_B + (NSUB == 1 ? 0 : wr * SUB_B);
+        const char* sx = smem + cur * 2 * TILE_B + TILE_B + (NSUB == 1 ? 0 : (wc >> 1) * SUB_B);
+        const int cob = NSUB == 1 ? wr * 64 : 0;
+        const int cib = NSUB == 1 ? wc * 64 : (wc & 1) * 64;
 #pragma unroll
         for (int ks = 0; ks < WgFrag<T>::KSTEPS; ++ks) {
-          u32x4 fa[4], fb[4];
+          u32x4 fb[MJ];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) fa[i] = WgFrag<T>::read(sd, ks, wr * 64 + i * 16, lane);
+          for (int j = 0; j < MJ; ++j) fb[j] = WgFrag<T>::read(sx, ks, cib + j * 16, lane);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) fb[j] = WgFrag<T>::read(sx, ks, wc * 64 + j * 16, lane);
+          for (int i = 0; i < MI; ++i) {
+            const u32x4 fa = WgFrag<T>::read(sd, ks, cob + i * 16, lane);
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) WgFrag<T>::mma(fa[i], fb[j], acc[i][j]);
+            for (int j = 0; j < MJ; ++j) WgFrag<T>::mma(fa, fb[j], acc[i][j]);
+          }
         }
       }
       if (more) store_chunk(cur ^ 1);
@@ -879,20 +894,49 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_wgrad_kernel(const Wgrad
     }
   }
 
-  // acc[i][j][r] = dw[co = co0 + wr*64 + i*16 + (lane>>4)*4 + r][ci = ci0 + wc*64 + j*16 + (lane&15)]
+  // acc[i][j][r] = dw[co = co0 + wr*MI*16 + i*16 + (lane>>4)*4 + r][ci = ci0 + wc*64 + j*16 + (lane&15)]
   const int fq = lane >> 4, fr = lane & 15;
   float* slab = p.slabs + (((size_t)bz * p.splits + sp) * taps + tap) * p.Cin * p.Cout;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < MJ; ++j) {
     const int ci = ci0 + wc * 64 + j * 16 + fr;
     if (ci >= p.Cin) continue;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int co = co0 + wr * 64 + i * 16 + fq * 4;
+    for (int i = 0; i < MI; ++i) {
+      const int co = co0 + wr * (MI * 16) + i * 16 + fq * 4;
       if (co >= p.Cout) continue;
       *reinterpret_cast<f32x4*>(slab + (size_t)ci * p.Cout + co) = acc[i][j];
     }
   }
+}
+
+// Launch the weight-gradient kernel; the 256 x 256 tile is used when the output channels fill it exactly.
+template <typename T>
+static int launch_wgrad(WgradDev& d, int batch, hipStream_t st, const char* name) {
+  static const char* force = getenv("SEGK_WGRAD_TILE");  // experiments: "small" / "big"
+  // a partial last input-channel tile wastes MFMA work but not loads, and loads are what bounds this kernel
+  bool big = d.Cin >= 256 && d.Cout % 256 == 0;
+  if (force && force[0] == 's') big = false;
+  const int tch = big ? 2 * TILE : TILE;
+  d.co_tiles = ceil_div(d.Cout, tch);
+  d.ci_tiles = ceil_div(d.Cin, tch);
+  const long long blocks = (long long)d.co_tiles * d.ci_tiles * d.R * d.R * d.splits;
+  if (blocks >= 2147483647LL) {
+    set_error("%s: too many tiles", name);
+    return SEGK_INVALID_ARG;
+  }
+  const int lds = 4 * 16384 * (big ? 2 : 1);
+  int rc;
+  if (big) {
+    rc = set_lds(conv_wgrad_kernel<T, 2>, lds, name);
+    if (rc != SEGK_OK) return rc;
+    conv_wgrad_kernel<T, 2><<<dim3((unsigned)blocks, (unsigned)batch), CONV_THREADS * 2, lds, st>>>(d);
+  } else {
+    rc = set_lds(conv_wgrad_kernel<T, 1>, lds, name);
+    if (rc != SEGK_OK) return rc;
+    conv_wgrad_kernel<T, 1><<<dim3((unsigned)blocks, (unsigned)batch), CONV_THREADS, lds, st>>>(d);
+  }
+  return SEGK_OK;
 }
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -1092,27 +1136,15 @@ extern "C" int segk_conv_wgrad(const segk_wgrad_args* a, segk_stream_t stream) {
   d.in = (const char*)a->in; d.dout = (const char*)a->dout;
   d.in_ld_b = (long long)a->in_ld * es; d.dout_ld_b = (long long)a->dout_ld * es;
   d.Cin = a->Cin; d.Cout = a->Cout; d.R = a->R; d.dil = a->dil; d.splits = a->splits;
-  d.co_tiles = ceil_div(a->Cout, TILE); d.ci_tiles = ceil_div(a->Cin, TILE);
   const int bp = a->dtype == SEGK_BF16 ? WgFrag<bf16_t>::BP : WgFrag<float>::BP;
   long long per = (d.M + a->splits - 1) / a->splits;
   per = (per + bp - 1) / bp * bp;
   d.per_split = per;
   d.slabs = a->slabs;
   d.in_batch_b = 0; d.dout_batch_b = 0;
-  const long long blocks = (long long)d.co_tiles * d.ci_tiles * a->R * a->R * a->splits;
-  SEGK_REQUIRE(blocks < 2147483647LL, "wgrad: too many tiles");
   hipStream_t st = (hipStream_t)stream;
-  const int lds = 4 * 16384;
-  int rc;
-  if (a->dtype == SEGK_BF16) {
-    rc = set_lds(conv_wgrad_kernel<bf16_t>, lds, "conv_wgrad");
-    if (rc != SEGK_OK) return rc;
-    conv_wgrad_kernel<bf16_t><<<(int)blocks, CONV_THREADS, lds, st>>>(d);
-  } else {
-    rc = set_lds(conv_wgrad_kernel<float>, lds, "conv_wgrad");
-    if (rc != SEGK_OK) return rc;
-    conv_wgrad_kernel<float><<<(int)blocks, CONV_THREADS, lds, st>>>(d);
-  }
+  int rc = a->dtype == SEGK_BF16 ? launch_wgrad<bf16_t>(d, 1, st, "conv_wgrad") : launch_wgrad<float>(d, 1, st, "conv_wgrad");
+  if (rc != SEGK_OK) return rc;
   SEGK_CHECK_LAUNCH("conv_wgrad");
   return SEGK_OK;
 }
@@ -1197,27 +1229,15 @@ extern "C" int segk_gemm_tn(const segk_gemm_tn_args* a, segk_stream_t stream) {
   d.in = (const char*)a->A; d.dout = (const char*)a->B;
   d.in_ld_b = (long long)a->lda * es; d.dout_ld_b = (long long)a->ldb * es;
   d.Cin = a->M; d.Cout = a->N; d.R = 1; d.dil = 1; d.splits = a->splits;
-  d.co_tiles = ceil_div(a->N, TILE); d.ci_tiles = ceil_div(a->M, TILE);
   const int bp = a->dtype == SEGK_BF16 ? WgFrag<bf16_t>::BP : WgFrag<float>::BP;
   long long per = ((long long)a->K + a->splits - 1) / a->splits;
   per = (per + bp - 1) / bp * bp;
   d.per_split = per;
   d.slabs = a->slabs;
   d.in_batch_b = a->a_batch * es; d.dout_batch_b = a->b_batch * es;
-  const long long blocks = (long long)d.co_tiles * d.ci_tiles * a->splits;
-  SEGK_REQUIRE(blocks < 2147483647LL, "gemm_tn: too many tiles");
   hipStream_t st = (hipStream_t)stream;
-  const int lds = 4 * 16384;
-  int rc;
-  if (a->dtype == SEGK_BF16) {
-    rc = set_lds(conv_wgrad_kernel<bf16_t>, lds, "gemm_tn");
-    if (rc != SEGK_OK) return rc;
-    conv_wgrad_kernel<bf16_t><<<dim3((unsigned)blocks, (unsigned)a->batch), CONV_THREADS, lds, st>>>(d);
-  } else {
-    rc = set_lds(conv_wgrad_kernel<float>, lds, "gemm_tn");
-    if (rc != SEGK_OK) return rc;
-    conv_wgrad_kernel<float><<<dim3((unsigned)blocks, (unsigned)a->batch), CONV_THREADS, lds, st>>>(d);
-  }
+  int rc = a->dtype == SEGK_BF16 ? launch_wgrad<bf16_t>(d, a->batch, st, "gemm_tn") : launch_wgrad<float>(d, a->batch, st, "gemm_tn");
+  if (rc != SEGK_OK) return rc;
   SEGK_CHECK_LAUNCH("gemm_tn");
   return SEGK_OK;
 }

@@ -182,11 +182,15 @@ def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=Fals
 
 
 def default_splits(M, Cin, Cout, R, dtype):
-    tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128) * R * R
+    """Parts of the pixel range so that the launch fills the chip: the 256x256-tile kernel (Cout a multiple of 256,
+    Cin at least 256) runs one workgroup per CU, the 128x128 one two."""
+    big = Cin >= 256 and Cout % 256 == 0
+    t = 256 if big else 128
+    tiles = ((Cin + t - 1) // t) * ((Cout + t - 1) // t) * R * R
+    target = 256 if big else 1024
     bp = 64 if dtype == torch.bfloat16 else 32
     chunks = max(1, (M + bp - 1) // bp)
-    s = max(1, min(1024 // tiles if tiles <= 1024 else 1, 64, chunks // 8 if chunks >= 8 else 1))
-    return s
+    return max(1, min(target // tiles if tiles <= target else 1, 64, chunks // 8 if chunks >= 8 else 1))
 
 
 def conv_wgrad(x, dout, N, H, W, R, dil, Cout_true, Cin_true, splits=None):
