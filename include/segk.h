@@ -208,6 +208,12 @@ int segk_bn_reduce(const double* partials, int rows, int C, double count, double
 int segk_bn_coeffs(const double* sums, const float* gamma, const float* beta, float eps, float momentum,
                    int legacy_clamp, float* running_mean, float* running_var, float* mean, float* inv_std,
                    float* scale, float* shift, int C, segk_stream_t stream);
+/* segk_bn_reduce followed by segk_bn_coeffs in one launch, for statistics that are not exchanged between ranks
+ * (a single rank, or a plain nn.BatchNorm2d inside the head: batchnorm.py:50-53).  sums ([2C+1] fp64) may be NULL. */
+int segk_bn_reduce_coeffs(const double* partials, int rows, int C, double count, const float* gamma,
+                          const float* beta, float eps, float momentum, int legacy_clamp, float* running_mean,
+                          float* running_var, float* mean, float* inv_std, float* scale, float* shift, double* sums,
+                          segk_stream_t stream);
 /* Evaluation mode (batchnorm.py:50-53 with training False): coefficients from running statistics. */
 int segk_bn_coeffs_eval(const float* running_mean, const float* running_var, const float* gamma,
                         const float* beta, float eps, float* mean, float* inv_std, float* scale, float* shift,

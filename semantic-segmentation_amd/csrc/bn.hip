@@ -199,12 +199,22 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_pm_kernel(
     const float* __restrict__ shift, int relu, const uint8_t* __restrict__ mask, float mask_scale,
     double* __restrict__ partials) {
   const PmThread t = pm_thread<VEC>(C, M);
+  extern __shared__ float cf[];  // [4][Cs]: mean, inv_std, scale, shift of the slab, loaded once per workgroup
+  for (int i = threadIdx.x; i < t.Cs; i += BN_THREADS) {
+    const int c = t.c_base + i;
+    cf[i] = mean[c];
+    cf[t.Cs + i] = inv_std[c];
+    cf[2 * t.Cs + i] = scale[c];
+    cf[3 * t.Cs + i] = shift[c];
+  }
+  __syncthreads();
   float a[VEC], b[VEC], mu[VEC], is[VEC], sc[VEC], sh[VEC];
   const int c0 = t.c_base + (t.active ? t.cgi * VEC : 0);
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
+    const int i = (t.active ? t.cgi * VEC : 0) + j;
     a[j] = b[j] = 0.f;
-    mu[j] = mean[c0 + j]; is[j] = inv_std[c0 + j]; sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j];
+    mu[j] = cf[i]; is[j] = cf[t.Cs + i]; sc[j] = cf[2 * t.Cs + i]; sh[j] = cf[3 * t.Cs + i];
   }
   if (t.active) {
     const long long step = t.rpb;
@@ -280,15 +290,30 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_pm_kernel(
     const float* __restrict__ scale, const float* __restrict__ shift, int relu, const uint8_t* __restrict__ mask,
     float mask_scale, const double* __restrict__ gsums, int eval) {
   const PmThread t = pm_thread<VEC>(C, M);
+  // the slab's per-channel coefficients go through LDS: one coalesced load per workgroup instead of 6 x VEC
+  // scattered loads (two of them fp64) per thread
+  extern __shared__ float cf[];  // [6][Cs]: scale, shift, mean, inv_std, sum_g / count, sum_g_xhat / count
+  {
+    const float inv_count = eval ? 0.f : (float)(1.0 / gsums[2 * C]);
+    for (int i = threadIdx.x; i < t.Cs; i += BN_THREADS) {
+      const int c = t.c_base + i;
+      cf[i] = scale[c];
+      cf[t.Cs + i] = shift[c];
+      cf[2 * t.Cs + i] = mean[c];
+      cf[3 * t.Cs + i] = inv_std[c];
+      cf[4 * t.Cs + i] = eval ? 0.f : (float)gsums[c] * inv_count;
+      cf[5 * t.Cs + i] = eval ? 0.f : (float)gsums[C + c] * inv_count;
+    }
+  }
+  __syncthreads();
   if (!t.active) return;
   const int c0 = t.c_base + t.cgi * VEC;
-  const float inv_count = eval ? 0.f : (float)(1.0 / gsums[2 * C]);
   float sc[VEC], sh[VEC], mu[VEC], is[VEC], k1[VEC], k2[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
-    sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; mu[j] = mean[c0 + j]; is[j] = inv_std[c0 + j];
-    k1[j] = eval ? 0.f : (float)gsums[c0 + j] * inv_count;
-    k2[j] = eval ? 0.f : (float)gsums[C + c0 + j] * inv_count;
+    const int i = t.cgi * VEC + j;
+    sc[j] = cf[i]; sh[j] = cf[t.Cs + i]; mu[j] = cf[2 * t.Cs + i]; is[j] = cf[3 * t.Cs + i];
+    k1[j] = cf[4 * t.Cs + i]; k2[j] = cf[5 * t.Cs + i];
   }
 #pragma unroll 2
   for (long long m = t.m0 + t.pr; m < t.m1; m += t.rpb) {
@@ -443,16 +468,12 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const double* __restrict
   if (blockIdx.x == 0 && threadIdx.x == 0) sums[n2] = count;
 }
 
-__global__ void bn_coeffs_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
-                                 const float* __restrict__ beta, float eps, float momentum, int legacy_clamp,
-                                 float* __restrict__ running_mean, float* __restrict__ running_var,
-                                 float* __restrict__ mean, float* __restrict__ inv_std, float* __restrict__ scale,
-                                 float* __restrict__ shift, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// global sums of one channel -> mean, inv_std, running statistics, scale, shift
+__device__ __forceinline__ void bn_coeff_one(double s, double q, double cnt, int c, const float* gamma, const float* beta,
+                                             float eps, float momentum, int legacy_clamp, float* running_mean,
+                                             float* running_var, float* mean, float* inv_std, float* scale,
+                                             float* shift) {
   // sums are fp64 end to end (exact squares, fp64 accumulation), so this cancellation is harmless
-  const double cnt = sums[2 * C];
-  const double s = sums[c], q = sums[C + c];
   const double mu = s / cnt;
   double sumvar = q - s * mu;
   if (sumvar < 0.0) sumvar = 0.0;
@@ -468,6 +489,55 @@ __global__ void bn_coeffs_kernel(const double* __restrict__ sums, const float* _
   const float sc = g * isf;
   scale[c] = sc;
   shift[c] = b - muf * sc;
+}
+
+__global__ void bn_coeffs_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float eps, float momentum, int legacy_clamp,
+                                 float* __restrict__ running_mean, float* __restrict__ running_var,
+                                 float* __restrict__ mean, float* __restrict__ inv_std, float* __restrict__ scale,
+                                 float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  bn_coeff_one(sums[c], sums[C + c], sums[2 * C], c, gamma, beta, eps, momentum, legacy_clamp, running_mean, running_var,
+               mean, inv_std, scale, shift);
+}
+
+// bn_reduce_kernel + bn_coeffs_kernel in one launch for statistics that need no exchange between ranks: a block
+// owns 8 channels (columns c and C + c of the partial rows), same fixed summation order as bn_reduce_kernel.
+__global__ __launch_bounds__(256) void bn_reduce_coeffs_kernel(const double* __restrict__ partials, int rows, int C,
+                                                                double count, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float eps, float momentum,
+                                                                int legacy_clamp, float* __restrict__ running_mean,
+                                                                float* __restrict__ running_var, float* __restrict__ mean,
+                                                                float* __restrict__ inv_std, float* __restrict__ scale,
+                                                                float* __restrict__ shift, double* __restrict__ sums) {
+  __shared__ double red[16][17];
+  const int j = threadIdx.x & 15, ph = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 8 + (j & 7);
+  const int n2 = 2 * C;
+  double s = 0.0;
+  if (ch < C) {
+    const int col = (j >> 3) * C + ch;
+#pragma unroll 4
+    for (int r = ph; r < rows; r += 16) s += partials[(size_t)r * n2 + col];
+  }
+  red[ph][j] = s;
+  __syncthreads();
+  if (threadIdx.x < 8 && ch < C) {
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      t0 += red[p][threadIdx.x];
+      t1 += red[p][threadIdx.x + 8];
+    }
+    if (sums) {
+      sums[ch] = t0;
+      sums[C + ch] = t1;
+    }
+    bn_coeff_one(t0, t1, count, ch, gamma, beta, eps, momentum, legacy_clamp, running_mean, running_var, mean, inv_std,
+                 scale, shift);
+  }
+  if (sums && blockIdx.x == 0 && threadIdx.x == 0) sums[n2] = count;
 }
 
 __global__ void bn_coeffs_eval_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var,
@@ -511,14 +581,16 @@ static int pm_vec(int C, std::initializer_list<int> lds, std::initializer_list<s
   return 1;
 }
 
-// grid of the pixel-major elementwise kernels: about eight pixels per thread
-static dim3 pm_apply_grid(long long M, int C, int vec) {
+// grid of the pixel-major elementwise kernels: about four workgroups per CU, and at least `min_rows` pixels per
+// thread so that the per-thread load of the channel coefficients is amortised
+static dim3 pm_apply_grid(long long M, int C, int vec, int min_rows = 4) {
   const int slab = BN_THREADS * vec;
   const int cg = (C < slab ? C : slab) / vec;
   const int rpb = BN_THREADS / cg;
-  long long gx = (M + rpb * 8 - 1) / (rpb * 8);
+  long long rpt = (M + (long long)rpb * 2048 - 1) / ((long long)rpb * 2048);
+  if (rpt < min_rows) rpt = min_rows;
+  long long gx = (M + rpb * rpt - 1) / (rpb * rpt);
   if (gx < 1) gx = 1;
-  if (gx > 4096) gx = 4096;
   return dim3((unsigned)gx, (unsigned)ceil_div(C, slab));
 }
 
@@ -601,6 +673,19 @@ extern "C" int segk_bn_coeffs(const double* sums, const float* gamma, const floa
   return SEGK_OK;
 }
 
+extern "C" int segk_bn_reduce_coeffs(const double* partials, int rows, int C, double count, const float* gamma,
+                                     const float* beta, float eps, float momentum, int legacy_clamp, float* running_mean,
+                                     float* running_var, float* mean, float* inv_std, float* scale, float* shift,
+                                     double* sums, segk_stream_t stream) {
+  SEGK_REQUIRE(partials && mean && inv_std && scale && shift && rows > 0 && C > 0 && count > 0.0,
+               "bn_reduce_coeffs: bad arguments rows=%d C=%d", rows, C);
+  bn_reduce_coeffs_kernel<<<ceil_div(C, 8), 256, 0, (hipStream_t)stream>>>(partials, rows, C, count, gamma, beta, eps,
+                                                                          momentum, legacy_clamp, running_mean,
+                                                                          running_var, mean, inv_std, scale, shift, sums);
+  SEGK_CHECK_LAUNCH("bn_reduce_coeffs");
+  return SEGK_OK;
+}
+
 extern "C" int segk_bn_coeffs_eval(const float* running_mean, const float* running_var, const float* gamma,
                                    const float* beta, float eps, float* mean, float* inv_std, float* scale,
                                    float* shift, int C, segk_stream_t stream) {
@@ -660,8 +745,9 @@ extern "C" int segk_bn_bwd_stats(const void* dz, int dz_dtype, int dz_ld, const 
     const long long M = (long long)N * HW;
     const int rows = pm_rows(M, C);
     const int vec = pm_vec(C, {x_ld, dz_ld}, {{x, x_dtype}, {dz, dz_dtype}}, mask);
+    const size_t lds = (size_t)4 * (C < BN_THREADS * vec ? C : BN_THREADS * vec) * sizeof(float);
 #define LAUNCH_BS(TG, TX)                                                                                           \
-  SEGK_DISPATCH_VEC(vec, V, (bn_bwd_stats_pm_kernel<TG, TX, V><<<dim3(rows, ceil_div(C, BN_THREADS * V)), BN_THREADS, 0, st>>>( \
+  SEGK_DISPATCH_VEC(vec, V, (bn_bwd_stats_pm_kernel<TG, TX, V><<<dim3(rows, ceil_div(C, BN_THREADS * V)), BN_THREADS, lds, st>>>( \
       (const TG*)dz, dz_ld, (const TX*)x, x_ld, M, C, mean, inv_std, scale, shift, relu, mask, mask_scale, partials)))
     if (dz_dtype == SEGK_BF16 && x_dtype == SEGK_BF16) { LAUNCH_BS(bf16_t, bf16_t); }
     else if (dz_dtype == SEGK_BF16) { LAUNCH_BS(bf16_t, float); }
@@ -699,8 +785,9 @@ extern "C" int segk_bn_bwd_apply(const void* dz, int dz_dtype, int dz_ld, const 
     const long long M = (long long)N * HW;
     const int vec = pm_vec(C, {x_ld, dz_ld, dx_ld}, {{x, x_dtype}, {dz, dz_dtype}, {dx, dx_dtype}}, mask);
     const dim3 grid = pm_apply_grid(M, C, vec);
+    const size_t lds = (size_t)6 * (C < BN_THREADS * vec ? C : BN_THREADS * vec) * sizeof(float);
 #define LAUNCH_BA(TG, TX)                                                                                            \
-  SEGK_DISPATCH_VEC(vec, V, (bn_bwd_apply_pm_kernel<TG, TX, V><<<grid, BN_THREADS, 0, st>>>(                         \
+  SEGK_DISPATCH_VEC(vec, V, (bn_bwd_apply_pm_kernel<TG, TX, V><<<grid, BN_THREADS, lds, st>>>(                       \
                                 (const TG*)dz, dz_ld, (const TX*)x, x_ld, (TG*)dx, dx_ld, M, C, mean, inv_std, scale, \
                                 shift, relu, mask, mask_scale, gsums, eval)))
     if (dz_dtype == SEGK_BF16 && x_dtype == SEGK_BF16) { LAUNCH_BA(bf16_t, bf16_t); }

@@ -77,6 +77,8 @@ SIGNATURES = {
     "segk_bn_reduce": [c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p],
     "segk_bn_coeffs": [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p,
                        c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "segk_bn_reduce_coeffs": [c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p, c_float, c_float, c_int,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "segk_bn_coeffs_eval": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_int, c_void_p],
     "segk_bn_apply": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,

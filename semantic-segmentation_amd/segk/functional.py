@@ -118,6 +118,18 @@ def _global_sums(local, sync):
     return local
 
 
+def _train_coeffs(partials, count, spec, gamma, beta):
+    """Partial statistic rows of this rank -> coefficient rows [mean, inv_std, scale, shift]; running statistics are
+    updated.  Synchronised layers exchange the [2C+1] vector in between, others finish in one launch."""
+    _check_count(count * (parallel.world_size() if spec.sync else 1))
+    if not spec.sync:
+        return ops.bn_reduce_coeffs(partials, count, gamma, beta, spec.eps, spec.momentum, spec.running_mean,
+                                    spec.running_var)
+    sums = _global_sums(ops.bn_reduce(partials, count), True)
+    return ops.bn_coeffs(sums, gamma, beta, spec.eps, spec.momentum, spec.running_mean, spec.running_var,
+                         legacy_clamp=config.legacy_clamp_eps())
+
+
 def _check_count(sums_host_count):
     if sums_host_count <= 1:
         raise ValueError("Expected more than 1 value per channel when training (batch-norm statistics)")
@@ -150,12 +162,7 @@ def unit_forward(x, weight, R, dil, geom, spec, gamma, beta, out, relu=True, dro
     raw = torch.empty((M, Cout), dtype=torch.float32, device=x.device)
     stats = ops.conv_fwd([(x, wp, R, dil)], N, H, W, Cout, raw, want_stats=spec.training, true_ck=[Cin])
     if spec.training:
-        local = ops.bn_reduce(stats, float(M))
-        total = M * (parallel.world_size() if spec.sync else 1)
-        _check_count(total)
-        sums = _global_sums(local, spec.sync)
-        coef = ops.bn_coeffs(sums, gamma, beta, spec.eps, spec.momentum, spec.running_mean, spec.running_var,
-                             legacy_clamp=config.legacy_clamp_eps() and spec.sync)
+        coef = _train_coeffs(stats, float(M), spec, gamma, beta)
     else:
         coef = ops.bn_coeffs_eval(spec.running_mean, spec.running_var, gamma, beta, spec.eps)
     mask, mask_scale = (None, 1.0)
@@ -471,11 +478,8 @@ class SyncBNFunction(torch.autograd.Function):
         C = shape[1]
         count = x.numel() // C
         if spec.training:
-            local = ops.bn_local_sums(xv, layout)
-            _check_count(count * (parallel.world_size() if spec.sync else 1))
-            sums = _global_sums(local, spec.sync)
-            coef = ops.bn_coeffs(sums, gamma, beta, spec.eps, spec.momentum, spec.running_mean, spec.running_var,
-                                 legacy_clamp=config.legacy_clamp_eps() and spec.sync)
+            partials, cnt = ops.bn_stat_partials(xv, layout)
+            coef = _train_coeffs(partials, cnt, spec, gamma, beta)
         else:
             coef = ops.bn_coeffs_eval(spec.running_mean, spec.running_var, gamma, beta, spec.eps)
         if layout == PM:

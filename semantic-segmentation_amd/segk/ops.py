@@ -386,14 +386,34 @@ def _bn_geom(x, layout):
     return N, C, HW, 0
 
 
-def bn_local_sums(x, layout):
-    """[2C+1] float64: per-channel sum, sum of squares, element count of THIS rank's tensor."""
+def bn_stat_partials(x, layout):
+    """([rows, 2, C] float64 partial sums / sums of squares of THIS rank's tensor, element count per channel)."""
     _dev(x)
     N, C, HW, ld = _bn_geom(x, layout)
     rows = call("segk_bn_stat_rows", layout, N, C, HW)
     partials = torch.empty((rows, 2, C), dtype=torch.float64, device=x.device)
     call("segk_bn_stats", _ptr(x), _dt(x), layout, N, C, HW, ld, _ptr(partials), _stream())
-    return bn_reduce(partials, float(N * HW))
+    return partials, float(N * HW)
+
+
+def bn_local_sums(x, layout):
+    """[2C+1] float64: per-channel sum, sum of squares, element count of THIS rank's tensor."""
+    partials, count = bn_stat_partials(x, layout)
+    return bn_reduce(partials, count)
+
+
+def bn_reduce_coeffs(partials, count, gamma, beta, eps, momentum, running_mean, running_var, legacy_clamp=False):
+    """bn_reduce + bn_coeffs in one launch (statistics that are not exchanged between ranks) -> coef [4, C]."""
+    rows, two, C = partials.shape
+    if partials.dtype != torch.float64 or not partials.is_contiguous():
+        raise ValueError("statistic partials are contiguous float64")
+    _dev(partials, gamma, beta, running_mean, running_var)
+    coef = torch.empty((4, C), dtype=torch.float32, device=partials.device)
+    r = _row_ptrs(coef)
+    call("segk_bn_reduce_coeffs", _ptr(partials), rows, C, ctypes.c_double(count), _ptr(gamma), _ptr(beta),
+         ctypes.c_float(eps), ctypes.c_float(momentum), 1 if legacy_clamp else 0, _ptr(running_mean),
+         _ptr(running_var), r[0], r[1], r[2], r[3], None, _stream())
+    return coef
 
 
 def bn_reduce(partials, count):
