@@ -49,9 +49,10 @@ def parse():
                     help="leave torch.backends.cudnn.benchmark off (MIOpen then picks the feeder's conv algorithms "
                          "heuristically instead of timing them in the first step)")
     ap.add_argument("--feeder-nchw", action="store_true", help="keep the feeder in NCHW memory format")
-    ap.add_argument("--sync-bn", choices=["auto", "on", "off"], default="auto",
-                    help="SynchronizedBatchNorm2d (HIP) in every layer; auto = only with more than one rank, as the "
-                         "reference's trainers decide (train.py:381-385)")
+    ap.add_argument("--sync-bn", choices=["auto", "on", "off"], default="on",
+                    help="SynchronizedBatchNorm2d (HIP) in every layer, the reference's --sync-bn (train.py:321-322); "
+                         "auto = only with more than one rank, its default when the flag is not given "
+                         "(train.py:381-385); off = torch's nn.BatchNorm2d (MIOpen) in the feeder")
     return ap.parse_args()
 
 
@@ -134,8 +135,8 @@ def main():
 
     torch.backends.cudnn.benchmark = not args.no_miopen_benchmark
     torch.manual_seed(1)  # the reference's --seed default; identical initial weights on every rank
-    model = DeepLab(backbone="resnet", output_stride=args.out_stride, num_classes=args.classes,
-                    sync_bn=(world > 1) if args.sync_bn == "auto" else (args.sync_bn == "on")).to(dev)
+    sync_bn = (world > 1) if args.sync_bn == "auto" else (args.sync_bn == "on")
+    model = DeepLab(backbone="resnet", output_stride=args.out_stride, num_classes=args.classes, sync_bn=sync_bn).to(dev)
     model.train()
     if feeder_amp:
         fmt = torch.contiguous_format if args.feeder_nchw else torch.channels_last
@@ -197,9 +198,12 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "DeepLabv3+ ResNet-101 OS%d, %d classes, %dx%d, batch %d/GPU: full train step "
-                                   "(feeder on PyTorch-ROCm %s, head on HIP kernels %s, CE ignore 255, SGD)"
+                                   "(feeder convolutions on PyTorch-ROCm %s, batch norm %s, head on HIP kernels %s, "
+                                   "CE ignore 255, SGD)"
                                    % (args.out_stride, args.classes, args.size, args.size, args.batch,
-                                      "bf16 autocast channels_last" if feeder_amp else "fp32", args.dtype),
+                                      "bf16 autocast channels_last" if feeder_amp else "fp32",
+                                      "HIP SynchronizedBatchNorm2d in all layers" if sync_bn else "nn.BatchNorm2d (MIOpen)",
+                                      args.dtype),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "final_loss": final_loss},
         }

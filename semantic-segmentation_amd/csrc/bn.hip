@@ -2,6 +2,10 @@
 // All HBM-bound.  Two layouts: pixel-major [M][ld] (head internals) and NCHW (the feeder's tensors).
 // Statistics are produced as per-block partial rows that a second kernel sums in index order, so the
 // result does not depend on scheduling (no float atomics).
+#include <algorithm>
+#include <initializer_list>
+#include <utility>
+
 #include "common.h"
 
 namespace segk {
@@ -175,10 +179,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_pm_kernel(const TX* __res
   block_reduce_pm<VEC, double>(a, b, t, partials + (size_t)blockIdx.x * 2 * C, C);
 }
 
-// g = dz * mask * mask_scale * [x*scale+shift > 0]
+// g = dz * mask * mask_scale * [activation > 0]; the activation is x*scale+shift, or, for layers that add a
+// residual before the ReLU, the layer's stored output `act`
 template <int VEC>
 __device__ __forceinline__ void grad_through_act(float (&gz)[VEC], const float (&xv)[VEC], const float* sc,
-                                                 const float* sh, int relu, const uint8_t* mask_p, float mask_scale) {
+                                                 const float* sh, int relu, const uint8_t* mask_p, float mask_scale,
+                                                 const float* act = nullptr) {
   if (mask_p) {
     float mk[VEC];
     load_mask<VEC>(mask_p, mk);
@@ -188,16 +194,18 @@ __device__ __forceinline__ void grad_through_act(float (&gz)[VEC], const float (
   if (relu) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
-      if (!(fmaf(xv[j], sc[j], sh[j]) > 0.f)) gz[j] = 0.f;
+      if (!((act ? act[j] : fmaf(xv[j], sc[j], sh[j])) > 0.f)) gz[j] = 0.f;
   }
 }
 
-template <typename TG, typename TX, int VEC>
+// RES: the layer added a residual before its ReLU; `act` (its stored output) then gives the ReLU pattern.  A template
+// flag, not a run-time test: a branch around a load keeps the compiler from issuing the row's loads together.
+template <typename TG, typename TX, int VEC, bool RES>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_pm_kernel(
     const TG* __restrict__ dz, int dz_ld, const TX* __restrict__ x, int x_ld, long long M, int C,
     const float* __restrict__ mean, const float* __restrict__ inv_std, const float* __restrict__ scale,
     const float* __restrict__ shift, int relu, const uint8_t* __restrict__ mask, float mask_scale,
-    double* __restrict__ partials) {
+    const TG* __restrict__ act, int act_ld, double* __restrict__ partials) {
   const PmThread t = pm_thread<VEC>(C, M);
   extern __shared__ float cf[];  // [4][Cs]: mean, inv_std, scale, shift of the slab, loaded once per workgroup
   for (int i = threadIdx.x; i < t.Cs; i += BN_THREADS) {
@@ -220,15 +228,17 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_pm_kernel(
     const long long step = t.rpb;
     long long m = t.m0 + t.pr;
     for (; m + step < t.m1; m += 2 * step) {
-      float gz[2][VEC], xv[2][VEC];
+      float gz[2][VEC], xv[2][VEC], av[2][VEC];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         load_vec<TG, VEC>(dz + (m + k * step) * dz_ld + c0, gz[k]);
         load_vec<TX, VEC>(x + (m + k * step) * x_ld + c0, xv[k]);
+        if (RES) load_vec<TG, VEC>(act + (m + k * step) * act_ld + c0, av[k]);
       }
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        grad_through_act<VEC>(gz[k], xv[k], sc, sh, relu, mask ? mask + (m + k * step) * C + c0 : nullptr, mask_scale);
+        grad_through_act<VEC>(gz[k], xv[k], sc, sh, relu, mask ? mask + (m + k * step) * C + c0 : nullptr, mask_scale,
+                              RES ? av[k] : nullptr);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           a[j] += gz[k][j];
@@ -237,10 +247,11 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_pm_kernel(
       }
     }
     for (; m < t.m1; m += step) {
-      float gz[VEC], xv[VEC];
+      float gz[VEC], xv[VEC], av[VEC];
       load_vec<TG, VEC>(dz + m * dz_ld + c0, gz);
       load_vec<TX, VEC>(x + m * x_ld + c0, xv);
-      grad_through_act<VEC>(gz, xv, sc, sh, relu, mask ? mask + m * C + c0 : nullptr, mask_scale);
+      if (RES) load_vec<TG, VEC>(act + m * act_ld + c0, av);
+      grad_through_act<VEC>(gz, xv, sc, sh, relu, mask ? mask + m * C + c0 : nullptr, mask_scale, RES ? av : nullptr);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         a[j] += gz[j];
@@ -251,12 +262,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_pm_kernel(
   block_reduce_pm<VEC, float>(a, b, t, partials + (size_t)blockIdx.x * 2 * C, C);
 }
 
-template <typename TX, typename TY, int VEC>
+template <typename TX, typename TY, int VEC, bool RES>
 __global__ __launch_bounds__(BN_THREADS) void bn_apply_pm_kernel(const TX* __restrict__ x, int x_ld, TY* __restrict__ y,
                                                                   int y_ld, long long M, int C,
                                                                   const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, int relu,
-                                                                  const uint8_t* __restrict__ mask, float mask_scale) {
+                                                                  const uint8_t* __restrict__ mask, float mask_scale,
+                                                                  const TY* __restrict__ res, int res_ld) {
   const PmThread t = pm_thread<VEC>(C, M);
   if (!t.active) return;
   const int c0 = t.c_base + t.cgi * VEC;
@@ -265,11 +277,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_pm_kernel(const TX* __res
   for (int j = 0; j < VEC; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
 #pragma unroll 4
   for (long long m = t.m0 + t.pr; m < t.m1; m += t.rpb) {
-    float v[VEC], o[VEC];
+    float v[VEC], o[VEC], rv[VEC];
     load_vec<TX, VEC>(x + m * x_ld + c0, v);
+    if (RES) load_vec<TY, VEC>(res + m * res_ld + c0, rv);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float r = fmaf(v[j], sc[j], sh[j]);
+      if (RES) r += rv[j];   // residual added before the ReLU (bottleneck shortcut)
       if (relu) r = r > 0.f ? r : 0.f;
       o[j] = r;
     }
@@ -283,12 +297,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_pm_kernel(const TX* __res
   }
 }
 
-template <typename TG, typename TX, int VEC>
+template <typename TG, typename TX, int VEC, bool RES>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_pm_kernel(
     const TG* __restrict__ dz, int dz_ld, const TX* __restrict__ x, int x_ld, TG* __restrict__ dx, int dx_ld,
     long long M, int C, const float* __restrict__ mean, const float* __restrict__ inv_std,
     const float* __restrict__ scale, const float* __restrict__ shift, int relu, const uint8_t* __restrict__ mask,
-    float mask_scale, const double* __restrict__ gsums, int eval) {
+    float mask_scale, const double* __restrict__ gsums, int eval, const TG* __restrict__ act, int act_ld,
+    TG* __restrict__ dres, int dres_ld) {
   const PmThread t = pm_thread<VEC>(C, M);
   // the slab's per-channel coefficients go through LDS: one coalesced load per workgroup instead of 6 x VEC
   // scattered loads (two of them fp64) per thread
@@ -317,10 +332,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_pm_kernel(
   }
 #pragma unroll 2
   for (long long m = t.m0 + t.pr; m < t.m1; m += t.rpb) {
-    float gz[VEC], xv[VEC], o[VEC];
+    float gz[VEC], xv[VEC], o[VEC], av[VEC];
     load_vec<TG, VEC>(dz + m * dz_ld + c0, gz);
     load_vec<TX, VEC>(x + m * x_ld + c0, xv);
-    grad_through_act<VEC>(gz, xv, sc, sh, relu, mask ? mask + m * C + c0 : nullptr, mask_scale);
+    if (RES) load_vec<TG, VEC>(act + m * act_ld + c0, av);
+    grad_through_act<VEC>(gz, xv, sc, sh, relu, mask ? mask + m * C + c0 : nullptr, mask_scale, RES ? av : nullptr);
+    if (RES) store_vec<TG, VEC>(dres + m * dres_ld + c0, gz);   // gradient of the residual input
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
       o[j] = eval ? sc[j] * gz[j] : sc[j] * (gz[j] - k1[j] - (xv[j] - mu[j]) * is[j] * k2[j]);
@@ -699,25 +716,33 @@ extern "C" int segk_bn_coeffs_eval(const float* running_mean, const float* runni
 
 extern "C" int segk_bn_apply(const void* x, int x_dtype, int x_ld, void* y, int y_dtype, int y_ld, int layout, int N,
                              int C, int HW, const float* scale, const float* shift, int relu, const uint8_t* mask,
-                             float mask_scale, segk_stream_t stream) {
+                             float mask_scale, const void* res, int res_ld, segk_stream_t stream) {
   SEGK_REQUIRE(x && y && scale && shift && valid_dtype(x_dtype) && valid_dtype(y_dtype),
                "bn_apply: null pointer or bad dtype");
   BN_COMMON_CHECK("bn_apply");
   hipStream_t st = (hipStream_t)stream;
   if (layout == SEGK_PM) {
-    SEGK_REQUIRE(x_ld >= C && y_ld >= C, "bn_apply: ld (%d,%d) < C %d", x_ld, y_ld, C);
+    SEGK_REQUIRE(x_ld >= C && y_ld >= C && (!res || res_ld >= C), "bn_apply: ld (%d,%d,%d) < C %d", x_ld, y_ld, res_ld, C);
     const long long M = (long long)N * HW;
-    const int vec = pm_vec(C, {x_ld, y_ld}, {{x, x_dtype}, {y, y_dtype}}, mask);
+    const int vec = res ? pm_vec(C, {x_ld, y_ld, res_ld}, {{x, x_dtype}, {y, y_dtype}, {res, y_dtype}}, mask)
+                        : pm_vec(C, {x_ld, y_ld}, {{x, x_dtype}, {y, y_dtype}}, mask);
     const dim3 grid = pm_apply_grid(M, C, vec);
 #define LAUNCH_APPLY(TX, TY)                                                                                       \
-  SEGK_DISPATCH_VEC(vec, V, (bn_apply_pm_kernel<TX, TY, V><<<grid, BN_THREADS, 0, st>>>(                           \
-                                (const TX*)x, x_ld, (TY*)y, y_ld, M, C, scale, shift, relu, mask, mask_scale)))
+  SEGK_DISPATCH_VEC(vec, V, {                                                                                      \
+    if (res)                                                                                                       \
+      bn_apply_pm_kernel<TX, TY, V, true><<<grid, BN_THREADS, 0, st>>>((const TX*)x, x_ld, (TY*)y, y_ld, M, C, scale, \
+                                                                       shift, relu, mask, mask_scale, (const TY*)res, res_ld); \
+    else                                                                                                           \
+      bn_apply_pm_kernel<TX, TY, V, false><<<grid, BN_THREADS, 0, st>>>((const TX*)x, x_ld, (TY*)y, y_ld, M, C, scale, \
+                                                                        shift, relu, mask, mask_scale, nullptr, 0); \
+  })
     if (x_dtype == SEGK_BF16 && y_dtype == SEGK_BF16) { LAUNCH_APPLY(bf16_t, bf16_t); }
     else if (x_dtype == SEGK_BF16) { LAUNCH_APPLY(bf16_t, float); }
     else if (y_dtype == SEGK_BF16) { LAUNCH_APPLY(float, bf16_t); }
     else { LAUNCH_APPLY(float, float); }
 #undef LAUNCH_APPLY
   } else {
+    SEGK_REQUIRE(!res, "bn_apply: the residual input needs the pixel-major layout");
     const long long planes = (long long)N * C;
     dim3 grid((unsigned)planes, nchw_apply_slices(planes, HW));
 #define LAUNCH_APPLY(TX, TY) \
@@ -735,26 +760,38 @@ extern "C" int segk_bn_apply(const void* x, int x_dtype, int x_ld, void* y, int 
 extern "C" int segk_bn_bwd_stats(const void* dz, int dz_dtype, int dz_ld, const void* x, int x_dtype, int x_ld,
                                  int layout, int N, int C, int HW, const float* mean, const float* inv_std,
                                  const float* scale, const float* shift, int relu, const uint8_t* mask,
-                                 float mask_scale, double* partials, segk_stream_t stream) {
+                                 float mask_scale, const void* act, int act_ld, double* partials,
+                                 segk_stream_t stream) {
   SEGK_REQUIRE(dz && x && mean && inv_std && scale && shift && partials && valid_dtype(dz_dtype) && valid_dtype(x_dtype),
                "bn_bwd_stats: null pointer or bad dtype");
   BN_COMMON_CHECK("bn_bwd_stats");
   hipStream_t st = (hipStream_t)stream;
   if (layout == SEGK_PM) {
-    SEGK_REQUIRE(x_ld >= C && dz_ld >= C, "bn_bwd_stats: ld (%d,%d) < C %d", dz_ld, x_ld, C);
+    SEGK_REQUIRE(x_ld >= C && dz_ld >= C && (!act || act_ld >= C), "bn_bwd_stats: ld (%d,%d,%d) < C %d", dz_ld, x_ld, act_ld, C);
     const long long M = (long long)N * HW;
     const int rows = pm_rows(M, C);
-    const int vec = pm_vec(C, {x_ld, dz_ld}, {{x, x_dtype}, {dz, dz_dtype}}, mask);
+    const int vec = act ? pm_vec(C, {x_ld, dz_ld, act_ld}, {{x, x_dtype}, {dz, dz_dtype}, {act, dz_dtype}}, mask)
+                        : pm_vec(C, {x_ld, dz_ld}, {{x, x_dtype}, {dz, dz_dtype}}, mask);
     const size_t lds = (size_t)4 * (C < BN_THREADS * vec ? C : BN_THREADS * vec) * sizeof(float);
 #define LAUNCH_BS(TG, TX)                                                                                           \
-  SEGK_DISPATCH_VEC(vec, V, (bn_bwd_stats_pm_kernel<TG, TX, V><<<dim3(rows, ceil_div(C, BN_THREADS * V)), BN_THREADS, lds, st>>>( \
-      (const TG*)dz, dz_ld, (const TX*)x, x_ld, M, C, mean, inv_std, scale, shift, relu, mask, mask_scale, partials)))
+  SEGK_DISPATCH_VEC(vec, V, {                                                                                       \
+    const dim3 grid_(rows, ceil_div(C, BN_THREADS * V));                                                            \
+    if (act)                                                                                                        \
+      bn_bwd_stats_pm_kernel<TG, TX, V, true><<<grid_, BN_THREADS, lds, st>>>(                                      \
+          (const TG*)dz, dz_ld, (const TX*)x, x_ld, M, C, mean, inv_std, scale, shift, relu, mask, mask_scale,      \
+          (const TG*)act, act_ld, partials);                                                                        \
+    else                                                                                                            \
+      bn_bwd_stats_pm_kernel<TG, TX, V, false><<<grid_, BN_THREADS, lds, st>>>(                                     \
+          (const TG*)dz, dz_ld, (const TX*)x, x_ld, M, C, mean, inv_std, scale, shift, relu, mask, mask_scale,      \
+          nullptr, 0, partials);                                                                                    \
+  })
     if (dz_dtype == SEGK_BF16 && x_dtype == SEGK_BF16) { LAUNCH_BS(bf16_t, bf16_t); }
     else if (dz_dtype == SEGK_BF16) { LAUNCH_BS(bf16_t, float); }
     else if (x_dtype == SEGK_BF16) { LAUNCH_BS(float, bf16_t); }
     else { LAUNCH_BS(float, float); }
 #undef LAUNCH_BS
   } else {
+    SEGK_REQUIRE(!act, "bn_bwd_stats: a stored activation needs the pixel-major layout");
     dim3 grid(C, nchw_rows(N, HW));
 #define LAUNCH_BS(TG, TX)                                                                                        \
   bn_bwd_stats_nchw_kernel<TG, TX><<<grid, BN_THREADS, 0, st>>>((const TG*)dz, (const TX*)x, N, C, HW, mean, inv_std, \
@@ -773,7 +810,7 @@ extern "C" int segk_bn_bwd_apply(const void* dz, int dz_dtype, int dz_ld, const 
                                  int dx_dtype, int dx_ld, int layout, int N, int C, int HW, const float* mean,
                                  const float* inv_std, const float* scale, const float* shift, int relu,
                                  const uint8_t* mask, float mask_scale, const double* gsums, int eval,
-                                 segk_stream_t stream) {
+                                 const void* act, int act_ld, void* dres, int dres_ld, segk_stream_t stream) {
   SEGK_REQUIRE(dz && x && dx && mean && inv_std && scale && shift && valid_dtype(dz_dtype) && valid_dtype(x_dtype),
                "bn_bwd_apply: null pointer or bad dtype");
   SEGK_REQUIRE(dx_dtype == dz_dtype, "bn_bwd_apply: dx dtype must equal dz dtype");
@@ -783,19 +820,31 @@ extern "C" int segk_bn_bwd_apply(const void* dz, int dz_dtype, int dz_ld, const 
   if (layout == SEGK_PM) {
     SEGK_REQUIRE(x_ld >= C && dz_ld >= C && dx_ld >= C, "bn_bwd_apply: ld (%d,%d,%d) < C %d", dz_ld, x_ld, dx_ld, C);
     const long long M = (long long)N * HW;
-    const int vec = pm_vec(C, {x_ld, dz_ld, dx_ld}, {{x, x_dtype}, {dz, dz_dtype}, {dx, dx_dtype}}, mask);
+    SEGK_REQUIRE((act != nullptr) == (dres != nullptr), "bn_bwd_apply: a stored activation and a residual gradient come together");
+    SEGK_REQUIRE((!act || act_ld >= C) && (!dres || dres_ld >= C), "bn_bwd_apply: ld (%d,%d) < C %d", act_ld, dres_ld, C);
+    int vec = pm_vec(C, {x_ld, dz_ld, dx_ld}, {{x, x_dtype}, {dz, dz_dtype}, {dx, dx_dtype}}, mask);
+    if (act) vec = std::min(vec, pm_vec(C, {act_ld}, {{act, dz_dtype}}, nullptr));
+    if (dres) vec = std::min(vec, pm_vec(C, {dres_ld}, {{dres, dz_dtype}}, nullptr));
     const dim3 grid = pm_apply_grid(M, C, vec);
     const size_t lds = (size_t)6 * (C < BN_THREADS * vec ? C : BN_THREADS * vec) * sizeof(float);
 #define LAUNCH_BA(TG, TX)                                                                                            \
-  SEGK_DISPATCH_VEC(vec, V, (bn_bwd_apply_pm_kernel<TG, TX, V><<<grid, BN_THREADS, lds, st>>>(                       \
-                                (const TG*)dz, dz_ld, (const TX*)x, x_ld, (TG*)dx, dx_ld, M, C, mean, inv_std, scale, \
-                                shift, relu, mask, mask_scale, gsums, eval)))
+  SEGK_DISPATCH_VEC(vec, V, {                                                                                        \
+    if (act)                                                                                                         \
+      bn_bwd_apply_pm_kernel<TG, TX, V, true><<<grid, BN_THREADS, lds, st>>>(                                        \
+          (const TG*)dz, dz_ld, (const TX*)x, x_ld, (TG*)dx, dx_ld, M, C, mean, inv_std, scale, shift, relu, mask,   \
+          mask_scale, gsums, eval, (const TG*)act, act_ld, (TG*)dres, dres_ld);                                      \
+    else                                                                                                             \
+      bn_bwd_apply_pm_kernel<TG, TX, V, false><<<grid, BN_THREADS, lds, st>>>(                                       \
+          (const TG*)dz, dz_ld, (const TX*)x, x_ld, (TG*)dx, dx_ld, M, C, mean, inv_std, scale, shift, relu, mask,   \
+          mask_scale, gsums, eval, nullptr, 0, nullptr, 0);                                                          \
+  })
     if (dz_dtype == SEGK_BF16 && x_dtype == SEGK_BF16) { LAUNCH_BA(bf16_t, bf16_t); }
     else if (dz_dtype == SEGK_BF16) { LAUNCH_BA(bf16_t, float); }
     else if (x_dtype == SEGK_BF16) { LAUNCH_BA(float, bf16_t); }
     else { LAUNCH_BA(float, float); }
 #undef LAUNCH_BA
   } else {
+    SEGK_REQUIRE(!act && !dres, "bn_bwd_apply: residual operands need the pixel-major layout");
     const long long planes = (long long)N * C;
     dim3 grid((unsigned)planes, nchw_apply_slices(planes, HW));
 #define LAUNCH_BA(TG, TX)                                                                                          \

@@ -462,10 +462,11 @@ def cross_entropy(logit, target, weight=None, ignore_index=255, size_average=Tru
 
 # ----------------------------------------------------------------- SyncBN ----
 class SyncBNFunction(torch.autograd.Function):
-    """Stand-alone batch norm on NCHW (or channels_last) tensors: the feeder's layers."""
+    """Stand-alone batch norm on NCHW (or channels_last) tensors: the feeder's layers.  Optionally with the ReLU
+    that follows it, and with the residual that a bottleneck block adds in between, in the same passes."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, mod, relu=False):
+    def forward(ctx, x, gamma, beta, mod, relu=False, residual=None):
         spec = _BNSpec(mod)
         layout, xv, shape = NCHW, x, x.shape
         v = pm_view_of(x) if x.dim() == 4 else None
@@ -475,8 +476,11 @@ class SyncBNFunction(torch.autograd.Function):
             xv = x.contiguous()
         if xv.dtype not in (torch.float32, torch.bfloat16):
             xv = xv.float()
-        C = shape[1]
-        count = x.numel() // C
+        rv = None
+        if residual is not None:
+            rv = pm_view_of(residual) if layout == PM and residual.shape == x.shape else None
+            if rv is None or rv.dtype != x.dtype or xv.dtype != x.dtype:
+                raise ValueError("the fused residual form needs channels_last input and residual of one dtype")
         if spec.training:
             partials, cnt = ops.bn_stat_partials(xv, layout)
             coef = _train_coeffs(partials, cnt, spec, gamma, beta)
@@ -484,18 +488,21 @@ class SyncBNFunction(torch.autograd.Function):
             coef = ops.bn_coeffs_eval(spec.running_mean, spec.running_var, gamma, beta, spec.eps)
         if layout == PM:
             y = torch.empty_like(x, memory_format=torch.channels_last)
-            ops.bn_apply(xv, pm_view_of(y), coef, PM, relu)
+            ops.bn_apply(xv, pm_view_of(y), coef, PM, relu, res=rv)
         else:
             y = torch.empty_like(xv)
             ops.bn_apply(xv, y, coef, NCHW, relu)
-        ctx.saved = (xv, coef, layout, spec.training, spec.sync, x.dtype, shape, relu)
+        # without a residual the ReLU pattern is recomputed from x*scale + shift; with one it is read from y
+        act = pm_view_of(y) if (rv is not None and relu) else None
+        ctx.saved = (xv, coef, layout, spec.training, spec.sync, x.dtype, shape, relu, act, rv is not None)
         ctx.affine = gamma is not None
         return y if y.dtype == x.dtype else y.to(x.dtype)
 
     @staticmethod
     def backward(ctx, g):
-        xv, coef, layout, training, sync, in_dtype, shape, relu = ctx.saved
+        xv, coef, layout, training, sync, in_dtype, shape, relu, act, has_res = ctx.saved
         C = shape[1]
+        dres = None
         if layout == PM:
             gv = pm_view_of(g)
             if gv is None or gv.dtype != xv.dtype:
@@ -503,20 +510,23 @@ class SyncBNFunction(torch.autograd.Function):
                 gv = pm_view_of(gc)
             dx = torch.empty(shape, dtype=xv.dtype, device=g.device, memory_format=torch.channels_last)
             dxv = pm_view_of(dx)
+            if has_res:
+                dres = torch.empty(shape, dtype=xv.dtype, device=g.device, memory_format=torch.channels_last)
         else:
             gv = g.to(xv.dtype).contiguous()
             dx = torch.empty_like(xv)
             dxv = dx
-        # the ReLU pattern is recomputed from x*scale + shift, so the fused form keeps no extra tensor
-        local = ops.bn_bwd_local_sums(gv, xv, coef, layout, relu)
+        partials, cnt = ops.bn_bwd_stat_partials(gv, xv, coef, layout, relu, act=act)
+        local = ops.bn_reduce(partials, cnt)
         dbeta, dgamma = local[:C].float(), local[C:2 * C].float()
         gs = _global_sums(local, sync and training)
-        ops.bn_bwd_apply(gv, xv, dxv, coef, gs, layout, relu, eval_mode=not training)
+        ops.bn_bwd_apply(gv, xv, dxv, coef, gs, layout, relu, eval_mode=not training, act=act,
+                         dres=pm_view_of(dres) if dres is not None else None)
         if dx.dtype != in_dtype:
             dx = dx.to(in_dtype)
         if not ctx.affine:
             dgamma = dbeta = None
-        return dx, dgamma, dbeta, None, None
+        return dx, dgamma, dbeta, None, None, dres
 
 
 # ------------------------------------------------------------ plain conv ----

@@ -49,10 +49,15 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         y = _bn_relu(self.bn1, self.relu, self.conv1(x))
         y = _bn_relu(self.bn2, self.relu, self.conv2(y))
-        y = self.bn3(self.conv3(y))
+        y = self.conv3(y)
         # the projection runs after the main path: autograd then sums the gradients that
         # reach x in the same order as the reference does, which keeps training bit-identical
-        y += x if self.downsample is None else self.downsample(x)
+        res = x if self.downsample is None else self.downsample(x)
+        fused = getattr(self.bn3, "forward_add_relu", None)
+        if fused is not None and self.bn3.can_fuse_residual(y, res):
+            return fused(y, res)
+        y = self.bn3(y)
+        y += res
         return self.relu(y)
 
 

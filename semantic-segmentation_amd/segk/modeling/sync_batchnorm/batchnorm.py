@@ -33,6 +33,21 @@ class _SynchronizedBatchNorm(_BatchNorm):
             raise ValueError("expected %d channels, got %d" % (self.num_features, input.shape[1]))
         return SF.SyncBNFunction.apply(input, self.weight, self.bias, self, True)
 
+    def forward_add_relu(self, input, residual):
+        """relu(self(input) + residual) in one pass: the tail of a bottleneck block.  Needs channels_last tensors of
+        one dtype; callers fall back to the separate operations otherwise."""
+        self._check_input_dim(input)
+        if input.shape[1] != self.num_features:
+            raise ValueError("expected %d channels, got %d" % (self.num_features, input.shape[1]))
+        return SF.SyncBNFunction.apply(input, self.weight, self.bias, self, True, residual)
+
+    @staticmethod
+    def can_fuse_residual(input, residual):
+        return (input.dim() == 4 and input.shape == residual.shape and input.dtype == residual.dtype
+                and input.dtype in (SF.torch.float32, SF.torch.bfloat16) and not input.is_contiguous()
+                and SF.pm_view_of(input) is not None and SF.pm_view_of(residual) is not None
+                and input.shape[1] % 4 == 0)
+
     def __data_parallel_replicate__(self, ctx, copy_id):
         raise RuntimeError("this SynchronizedBatchNorm runs one process per GPU (torch.distributed); "
                            "nn.DataParallel replication is not supported")

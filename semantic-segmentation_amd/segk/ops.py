@@ -457,45 +457,79 @@ def _mask_check(mask, x):
     _dev(mask)
 
 
-def bn_apply(x, y, coef, layout, relu, mask=None, mask_scale=1.0):
+def _pm_operand(t, like, name, layout):
+    """(pointer, ld) of an optional pixel-major operand shaped like `like`."""
+    if t is None:
+        return None, 0
+    if layout != PM:
+        raise ValueError("%s needs the pixel-major layout" % name)
+    _dev(t)
+    ld, c = _pm(t)
+    if t.shape != like.shape:
+        raise ValueError("%s shape %s != %s" % (name, tuple(t.shape), tuple(like.shape)))
+    return _ptr(t), ld
+
+
+def bn_apply(x, y, coef, layout, relu, mask=None, mask_scale=1.0, res=None):
+    """y = relu?(x*scale + shift [+ res]) * mask; res (pixel-major, y's dtype) is the shortcut of a residual block."""
     _dev(x, y, coef)
     N, C, HW, x_ld = _bn_geom(x, layout)
     y_ld = _pm(y)[0] if layout == PM else 0
     if y.shape != x.shape:
         raise ValueError("bn_apply output shape %s != input shape %s" % (tuple(y.shape), tuple(x.shape)))
     _mask_check(mask, x)
+    if res is not None and res.dtype != y.dtype:
+        raise ValueError("the residual input has the output's dtype")
+    rp, r_ld = _pm_operand(res, y, "residual", layout)
     r = _row_ptrs(coef)
     call("segk_bn_apply", _ptr(x), _dt(x), x_ld, _ptr(y), _dt(y), y_ld, layout, N, C, HW, r[2], r[3],
-         1 if relu else 0, _ptr(mask), ctypes.c_float(mask_scale), _stream())
+         1 if relu else 0, _ptr(mask), ctypes.c_float(mask_scale), rp, r_ld, _stream())
     return y
 
 
-def bn_bwd_local_sums(dz, x, coef, layout, relu, mask=None, mask_scale=1.0):
-    """[2C+1] float64: sum g, sum g*xhat, count for this rank (g = dz through dropout and ReLU)."""
+def bn_bwd_stat_partials(dz, x, coef, layout, relu, mask=None, mask_scale=1.0, act=None):
+    """([rows, 2, C] float64 partial sums of g and g*xhat, count) for this rank (g = dz through dropout and ReLU);
+    act = the layer's stored output when a residual was added before the ReLU."""
     _dev(dz, x, coef)
     N, C, HW, x_ld = _bn_geom(x, layout)
     dz_ld = _pm(dz)[0] if layout == PM else 0
     if layout == NCHW and not dz.is_contiguous():
         raise ValueError("NCHW gradient must be contiguous")
     _mask_check(mask, x)
+    if act is not None and act.dtype != dz.dtype:
+        raise ValueError("the stored activation has the gradient's dtype")
+    ap, a_ld = _pm_operand(act, x, "stored activation", layout)
     rows = call("segk_bn_stat_rows", layout, N, C, HW)
     partials = torch.empty((rows, 2, C), dtype=torch.float64, device=x.device)
     r = _row_ptrs(coef)
     call("segk_bn_bwd_stats", _ptr(dz), _dt(dz), dz_ld, _ptr(x), _dt(x), x_ld, layout, N, C, HW, r[0], r[1], r[2], r[3],
-         1 if relu else 0, _ptr(mask), ctypes.c_float(mask_scale), _ptr(partials), _stream())
-    return bn_reduce(partials, float(N * HW))
+         1 if relu else 0, _ptr(mask), ctypes.c_float(mask_scale), ap, a_ld, _ptr(partials), _stream())
+    return partials, float(N * HW)
 
 
-def bn_bwd_apply(dz, x, dx, coef, gsums, layout, relu, mask=None, mask_scale=1.0, eval_mode=False):
+def bn_bwd_local_sums(dz, x, coef, layout, relu, mask=None, mask_scale=1.0, act=None):
+    """[2C+1] float64: sum g, sum g*xhat, count for this rank."""
+    partials, count = bn_bwd_stat_partials(dz, x, coef, layout, relu, mask, mask_scale, act)
+    return bn_reduce(partials, count)
+
+
+def bn_bwd_apply(dz, x, dx, coef, gsums, layout, relu, mask=None, mask_scale=1.0, eval_mode=False, act=None,
+                 dres=None):
+    """dx from the global sums; dres (optional, dz's dtype) receives the gradient of the residual input."""
     _dev(dz, x, dx, coef, gsums)
     N, C, HW, x_ld = _bn_geom(x, layout)
     dz_ld = _pm(dz)[0] if layout == PM else 0
     dx_ld = _pm(dx)[0] if layout == PM else 0
     _mask_check(mask, x)
+    for t, nm in ((act, "stored activation"), (dres, "residual gradient")):
+        if t is not None and t.dtype != dz.dtype:
+            raise ValueError("the %s has the gradient's dtype" % nm)
+    ap, a_ld = _pm_operand(act, x, "stored activation", layout)
+    dp, d_ld = _pm_operand(dres, x, "residual gradient", layout)
     r = _row_ptrs(coef)
     call("segk_bn_bwd_apply", _ptr(dz), _dt(dz), dz_ld, _ptr(x), _dt(x), x_ld, _ptr(dx), _dt(dx), dx_ld, layout, N,
          C, HW, r[0], r[1], r[2], r[3], 1 if relu else 0, _ptr(mask), ctypes.c_float(mask_scale), _ptr(gsums),
-         1 if eval_mode else 0, _stream())
+         1 if eval_mode else 0, ap, a_ld, dp, d_ld, _stream())
     return dx
 
 

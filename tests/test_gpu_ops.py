@@ -508,3 +508,34 @@ def test_lincomb_and_dot(ops, dtype, tol):
     assert relerr(out2, 0.7 * x.double()) < tol
     d = ops.dot(x, y)
     assert abs(float(d) - float((x.double() * y.double()).sum())) < 1e-5 * float((x.double() * y.double()).abs().sum())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_bn_residual_relu_fused(ops, dtype, tol):
+    """relu(bn(x) + res) and its three gradients (x, res, gamma/beta sums) against autograd in fp64."""
+    from segk._lib import PM
+    M, C = 3 * 7 * 5, 48
+    x = T(gen.normal(9, "brx", (M, C), std=2.0, mean=0.3), dtype)
+    res = T(gen.normal(9, "brr", (M, C)), dtype)
+    g = T(gen.normal(9, "brg", (M, C)), dtype)
+    gamma = T(gen.uniform(9, "brga", (C,), 0.5, 1.5))
+    beta = T(gen.normal(9, "brb", (C,), std=0.3))
+    coef = ops.bn_coeffs(ops.bn_local_sums(x, PM), gamma, beta, 1e-5, 0.1, None, None)
+    y = torch.empty_like(x)
+    ops.bn_apply(x, y, coef, PM, True, res=res)
+    xr = x.double().requires_grad_(True)
+    rr = res.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yr = torch.relu(F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5) + rr)
+    assert relerr(y, yr.detach()) < tol
+    # backward on the kernel's own activation pattern
+    yr2 = (F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5) + rr) * (y > 0).double()
+    yr2.backward(g.double())
+    sums = ops.bn_bwd_local_sums(g, x, coef, PM, True, act=y)
+    dx, dres = torch.empty_like(x), torch.empty_like(x)
+    ops.bn_bwd_apply(g, x, dx, coef, sums, PM, True, act=y, dres=dres)
+    assert relerr(dx, xr.grad) < tol
+    assert relerr(dres, rr.grad) < tol
+    assert relerr(sums[:C], br.grad) < tol
+    xhat_scale = relerr(sums[C:2 * C] * coef[1].double(), gr.grad * coef[1].double())  # sum g*xhat = dgamma
+    assert xhat_scale < tol
