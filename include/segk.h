@@ -199,8 +199,11 @@ int segk_bn_stats(const void* x, int dtype, int layout, int N, int C, int HW, in
                   segk_stream_t stream);
 int segk_bn_stat_rows(int layout, int N, int C, int HW);
 /* Sum `rows` partial rows in index order: sums[0..C) = first sum, sums[C..2C) = second sum, sums[2C] = count.
- * The [2C+1] fp64 vector is what ranks all-reduce (replaces ReduceAddCoalesced, batchnorm.py:101-102). */
-int segk_bn_reduce(const double* partials, int rows, int C, double count, double* sums, segk_stream_t stream);
+ * The [2C+1] fp64 vector is what ranks all-reduce (replaces ReduceAddCoalesced, batchnorm.py:101-102).
+ * sums_f32 (NULL, or [2C] fp32) receives the same two sums rounded to fp32: in the backward pass they are this
+ * rank's d(beta) and d(gamma). */
+int segk_bn_reduce(const double* partials, int rows, int C, double count, double* sums, float* sums_f32,
+                   segk_stream_t stream);
 /* Global sums -> mean, inv_std, running statistics and the affine coefficients
  * scale = gamma*inv_std, shift = beta - mean*scale (batchnorm.py:113-125 and :73).
  * legacy_clamp != 0: inv_std = clamp(var, eps)^-1/2 (batchnorm.py:125); 0: (var + eps)^-1/2 (F.batch_norm,

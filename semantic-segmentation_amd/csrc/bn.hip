@@ -461,7 +461,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_nchw_kernel(
 // Block = 16 columns x 16 row phases; each thread sums rows phase, phase+16, ... of its column, then the 16
 // phase sums of a column are added in phase order: a fixed summation order, independent of scheduling.
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const double* __restrict__ partials, int rows, int C,
-                                                         double count, double* __restrict__ sums) {
+                                                         double count, double* __restrict__ sums,
+                                                         float* __restrict__ sums_f32) {
   __shared__ double red[16][17];
   const int col = blockIdx.x * 16 + (threadIdx.x & 15);
   const int ph = threadIdx.x >> 4;
@@ -480,6 +481,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const double* __restrict
 #pragma unroll
       for (int p = 0; p < 16; ++p) t += red[p][threadIdx.x];
       sums[c] = t;
+      if (sums_f32) sums_f32[c] = (float)t;
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) sums[n2] = count;
@@ -671,10 +673,10 @@ extern "C" int segk_bn_stats(const void* x, int dtype, int layout, int N, int C,
   return SEGK_OK;
 }
 
-extern "C" int segk_bn_reduce(const double* partials, int rows, int C, double count, double* sums,
+extern "C" int segk_bn_reduce(const double* partials, int rows, int C, double count, double* sums, float* sums_f32,
                               segk_stream_t stream) {
   SEGK_REQUIRE(partials && sums && rows > 0 && C > 0, "bn_reduce: bad arguments rows=%d C=%d", rows, C);
-  bn_reduce_kernel<<<ceil_div(2 * C, 16), 256, 0, (hipStream_t)stream>>>(partials, rows, C, count, sums);
+  bn_reduce_kernel<<<ceil_div(2 * C, 16), 256, 0, (hipStream_t)stream>>>(partials, rows, C, count, sums, sums_f32);
   SEGK_CHECK_LAUNCH("bn_reduce");
   return SEGK_OK;
 }

@@ -74,7 +74,7 @@ SIGNATURES = {
     "segk_dot_partial_rows": [c_ll],
     "segk_bn_stats": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "segk_bn_stat_rows": [c_int, c_int, c_int, c_int],
-    "segk_bn_reduce": [c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p],
+    "segk_bn_reduce": [c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p, c_void_p],
     "segk_bn_coeffs": [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p,
                        c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "segk_bn_reduce_coeffs": [c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p, c_float, c_float, c_int,

@@ -184,8 +184,9 @@ def unit_backward(rec, dz, need_dw=True):
     N, H, W = rec.geom
     M = N * H * W
     C = rec.Cout
-    local = ops.bn_bwd_local_sums(dz, rec.raw, rec.coef, PM, rec.relu, rec.mask, rec.mask_scale)
-    dbeta, dgamma = local[:C].float(), local[C:2 * C].float()
+    partials, cnt = ops.bn_bwd_stat_partials(dz, rec.raw, rec.coef, PM, rec.relu, rec.mask, rec.mask_scale)
+    local, dgb = ops.bn_reduce(partials, cnt, want_f32=True)
+    dbeta, dgamma = dgb[0], dgb[1]
     gs = _global_sums(local, rec.sync and rec.training)
     cpad = ops.round_up(C, 32)
     alloc = torch.zeros if cpad != C else torch.empty
@@ -517,8 +518,8 @@ class SyncBNFunction(torch.autograd.Function):
             dx = torch.empty_like(xv)
             dxv = dx
         partials, cnt = ops.bn_bwd_stat_partials(gv, xv, coef, layout, relu, act=act)
-        local = ops.bn_reduce(partials, cnt)
-        dbeta, dgamma = local[:C].float(), local[C:2 * C].float()
+        local, dgb = ops.bn_reduce(partials, cnt, want_f32=True)
+        dbeta, dgamma = dgb[0], dgb[1]
         gs = _global_sums(local, sync and training)
         ops.bn_bwd_apply(gv, xv, dxv, coef, gs, layout, relu, eval_mode=not training, act=act,
                          dres=pm_view_of(dres) if dres is not None else None)

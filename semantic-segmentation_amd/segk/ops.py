@@ -416,14 +416,16 @@ def bn_reduce_coeffs(partials, count, gamma, beta, eps, momentum, running_mean, 
     return coef
 
 
-def bn_reduce(partials, count):
-    """[rows, 2, C] float64 partial rows -> [2C+1] float64 (two per-channel sums, then the count)."""
+def bn_reduce(partials, count, want_f32=False):
+    """[rows, 2, C] float64 partial rows -> [2C+1] float64 (two per-channel sums, then the count); with want_f32
+    also the two sums as a [2, C] float32 tensor from the same launch."""
     rows, two, C = partials.shape
     if partials.dtype != torch.float64 or not partials.is_contiguous():
         raise ValueError("statistic partials are contiguous float64")
     sums = torch.empty((2 * C + 1,), dtype=torch.float64, device=partials.device)
-    call("segk_bn_reduce", _ptr(partials), rows, C, ctypes.c_double(count), _ptr(sums), _stream())
-    return sums
+    f32 = torch.empty((2, C), dtype=torch.float32, device=partials.device) if want_f32 else None
+    call("segk_bn_reduce", _ptr(partials), rows, C, ctypes.c_double(count), _ptr(sums), _ptr(f32), _stream())
+    return (sums, f32) if want_f32 else sums
 
 
 def bn_coeffs(sums, gamma, beta, eps, momentum, running_mean, running_var, legacy_clamp=False):
