@@ -105,6 +105,56 @@ __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float (&v)[4]) {
   *reinterpret_cast<u32x2*>(p) = t;
 }
 
+// Vector form for channel counts that are multiples of 8 with 16-byte aligned rows: block (chunk, n) owns 128
+// channels = 16 groups of 8 channels (one 16-byte load for bf16, two for fp32) x 16 pixel phases, four rows in flight
+// per thread; twice as many workgroups as the scalar form and 8x fewer load instructions.
+template <typename T>
+__global__ __launch_bounds__(256) void pool_sum_vec_kernel(const T* __restrict__ x, int ld, int HW, int C, float scale,
+                                                            float* __restrict__ out) {
+  __shared__ float red[16][129];
+  const int n = blockIdx.y;
+  const int g = threadIdx.x & 15, ph = threadIdx.x >> 4;
+  const int c0 = blockIdx.x * 128 + g * 8;
+  float a[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = 0.f;
+  if (c0 < C) {
+    const T* base = x + (size_t)n * HW * ld + c0;
+    int p = ph;
+    for (; p + 48 < HW; p += 64) {
+      float v[4][8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        load4<T>(base + (size_t)(p + 16 * k) * ld, *reinterpret_cast<float(*)[4]>(&v[k][0]));
+        load4<T>(base + (size_t)(p + 16 * k) * ld + 4, *reinterpret_cast<float(*)[4]>(&v[k][4]));
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += v[k][j];
+    }
+    for (; p < HW; p += 16) {
+      float v[8];
+      load4<T>(base + (size_t)p * ld, *reinterpret_cast<float(*)[4]>(&v[0]));
+      load4<T>(base + (size_t)p * ld + 4, *reinterpret_cast<float(*)[4]>(&v[4]));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[ph][g * 8 + j] = a[j];
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int c = blockIdx.x * 128 + threadIdx.x;
+    if (c < C) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) s += red[q][threadIdx.x];
+      out[(size_t)n * C + c] = s * scale;
+    }
+  }
+}
+
 // pixel-major -> pixel-major; thread = (output pixel, group of 4 channels); C % 4 == 0
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void upsample_fwd_pm_kernel(const TI* __restrict__ in, int in_ld, int C, int Hi, int Wi,
@@ -298,9 +348,14 @@ extern "C" int segk_pool_sum(const void* x, int dtype, int ld, int N, int HW, in
   SEGK_REQUIRE(x && out && valid_dtype(dtype), "pool_sum: null pointer or bad dtype");
   SEGK_REQUIRE(N > 0 && N <= 65535 && HW > 0 && C > 0 && ld >= C, "pool_sum: bad shape N=%d HW=%d C=%d ld=%d", N, HW, C,
                ld);
-  dim3 grid(ceil_div(C, 256), N);
   hipStream_t st = (hipStream_t)stream;
-  SEGK_DISPATCH_DTYPE(dtype, T, (pool_sum_kernel<T><<<grid, 256, 0, st>>>((const T*)x, ld, HW, C, scale, out)));
+  if (C % 8 == 0 && ld % 8 == 0 && aligned_to(x, 16)) {
+    dim3 grid(ceil_div(C, 128), N);
+    SEGK_DISPATCH_DTYPE(dtype, T, (pool_sum_vec_kernel<T><<<grid, 256, 0, st>>>((const T*)x, ld, HW, C, scale, out)));
+  } else {
+    dim3 grid(ceil_div(C, 256), N);
+    SEGK_DISPATCH_DTYPE(dtype, T, (pool_sum_kernel<T><<<grid, 256, 0, st>>>((const T*)x, ld, HW, C, scale, out)));
+  }
   SEGK_CHECK_LAUNCH("pool_sum");
   return SEGK_OK;
 }
