@@ -126,7 +126,7 @@ def main():
     rank, world = parallel.init_from_env()
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cd = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -184,9 +184,9 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
 

@@ -111,10 +111,9 @@ class _BNSpec:
 
 
 def _global_sums(local, sync):
+    """All-reduce (SUM) the [2C+1] statistics vector in place across ranks; identity for unsynchronised layers."""
     if sync:
-        g = local.clone()
-        parallel.all_reduce_sum_(g)
-        return g
+        parallel.all_reduce_sum_(local)
     return local
 
 

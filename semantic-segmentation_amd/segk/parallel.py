@@ -34,7 +34,9 @@ def init_from_env(backend=None):
     if ws <= 1 or (dist.is_available() and dist.is_initialized()):
         return rank(), world_size()
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # SEGK_DIST_BACKEND=gloo: rehearse a multi-rank job on a box with fewer GPUs than ranks (RCCL refuses two
+        # ranks on one device)
+        backend = os.environ.get("SEGK_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
