@@ -29,6 +29,7 @@ import torch.distributed as dist  # noqa: E402
 
 BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X bf16 MFMA, dense
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X fp32 MFMA
+HBM_PEAK_GBS = 8000.0             # MI355X HBM3E (about 6300 achievable)
 
 
 def parse():
@@ -183,6 +184,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    conv_summ = timer.summary() if timer is not None else None   # the convolution figures: timed steps only
+    if timer is not None:
+        # one extra, untimed step with events around the ~420 memory-bound batch-norm launches as well (their
+        # 840 events would cost the timed region about 1.5 %)
+        timer.hbm = True
+        step(args.warmup + args.steps)
+        torch.cuda.synchronize()
     ops.TIMER = None
     final_loss = float(loss.detach())
     if world > 1:
@@ -209,7 +217,7 @@ def main():
         }
         if timer is not None:
             summ = timer.summary()
-            dom = summ.get("conv_fwd_kernel")
+            dom = conv_summ.get("conv_fwd_kernel")
             if dom:
                 peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MATRIX_PEAK_TFLOPS
                 ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
@@ -221,13 +229,23 @@ def main():
                                     "forward + data gradient, all %d launches of the timed steps)" % dom["launches"],
                                     "avg_launch_ms": dom["avg_ms"],
                                     "share_of_step": dom["ms"] / (1000.0 * elapsed)}
-            wg = summ.get("conv_wgrad_kernel")
+            wg = conv_summ.get("conv_wgrad_kernel")
             if wg:
                 peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MATRIX_PEAK_TFLOPS
                 ach = wg["flops"] / (wg["ms"] * 1e-3) / 1e12
                 line["roofline_wgrad"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                                           "frac": ach / peak, "avg_launch_ms": wg["avg_ms"],
                                           "share_of_step": wg["ms"] / (1000.0 * elapsed)}
+            bn = [v for k, v in summ.items() if k.startswith("bn_")]
+            if bn:
+                nbytes, ms = sum(v["flops"] for v in bn), sum(v["ms"] for v in bn)
+                ach = nbytes / (ms * 1e-3) / 1e9
+                line["roofline_hbm"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": ach / HBM_PEAK_GBS,
+                                        "kernel": "bn_stats / bn_apply / bn_bwd_stats / bn_bwd_apply (pixel-major batch "
+                                                  "norm, %d launches of one extra step after the timed region; algorithmic bytes = every "
+                                                  "operand tensor once)" % sum(v["launches"] for v in bn),
+                                        "share_of_step": ms / (1000.0 * elapsed / args.steps)}
         if world == 1 and not args.no_cpu_baseline:
             del model, opt, buckets
             torch.cuda.empty_cache()

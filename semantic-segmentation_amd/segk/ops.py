@@ -64,7 +64,8 @@ class KernelTimer:
     record its algorithmic FLOPs.  None (default) = no events are created."""
 
     def __init__(self):
-        self.records = {}   # name -> list of (flops, start_event, end_event)
+        self.records = {}   # name -> list of (flops or bytes, start_event, end_event)
+        self.hbm = False    # also time the memory-bound batch-norm launches (their record holds algorithmic bytes)
 
     def start(self):
         e = torch.cuda.Event(enable_timing=True)
@@ -87,6 +88,20 @@ class KernelTimer:
 
 
 TIMER = None
+
+
+def _hbm_start():
+    return TIMER.start() if (TIMER is not None and TIMER.hbm) else None
+
+
+def _hbm_stop(name, nbytes, t0):
+    if t0 is not None:
+        TIMER.stop(name, float(nbytes), t0)
+
+
+def _nbytes(*ts):
+    """Algorithmic bytes of full-tensor operands (each touched once)."""
+    return sum(t.numel() * t.element_size() for t in ts if t is not None)
 
 
 # ------------------------------------------------------------------ layout ----
@@ -392,7 +407,9 @@ def bn_stat_partials(x, layout):
     N, C, HW, ld = _bn_geom(x, layout)
     rows = call("segk_bn_stat_rows", layout, N, C, HW)
     partials = torch.empty((rows, 2, C), dtype=torch.float64, device=x.device)
+    t0 = _hbm_start()
     call("segk_bn_stats", _ptr(x), _dt(x), layout, N, C, HW, ld, _ptr(partials), _stream())
+    _hbm_stop("bn_stats", _nbytes(x), t0)
     return partials, float(N * HW)
 
 
@@ -484,8 +501,10 @@ def bn_apply(x, y, coef, layout, relu, mask=None, mask_scale=1.0, res=None):
         raise ValueError("the residual input has the output's dtype")
     rp, r_ld = _pm_operand(res, y, "residual", layout)
     r = _row_ptrs(coef)
+    t0 = _hbm_start()
     call("segk_bn_apply", _ptr(x), _dt(x), x_ld, _ptr(y), _dt(y), y_ld, layout, N, C, HW, r[2], r[3],
          1 if relu else 0, _ptr(mask), ctypes.c_float(mask_scale), rp, r_ld, _stream())
+    _hbm_stop("bn_apply", _nbytes(x, y, res, mask), t0)
     return y
 
 
@@ -504,8 +523,10 @@ def bn_bwd_stat_partials(dz, x, coef, layout, relu, mask=None, mask_scale=1.0, a
     rows = call("segk_bn_stat_rows", layout, N, C, HW)
     partials = torch.empty((rows, 2, C), dtype=torch.float64, device=x.device)
     r = _row_ptrs(coef)
+    t0 = _hbm_start()
     call("segk_bn_bwd_stats", _ptr(dz), _dt(dz), dz_ld, _ptr(x), _dt(x), x_ld, layout, N, C, HW, r[0], r[1], r[2], r[3],
          1 if relu else 0, _ptr(mask), ctypes.c_float(mask_scale), ap, a_ld, _ptr(partials), _stream())
+    _hbm_stop("bn_bwd_stats", _nbytes(dz, x, act, mask), t0)
     return partials, float(N * HW)
 
 
@@ -529,9 +550,11 @@ def bn_bwd_apply(dz, x, dx, coef, gsums, layout, relu, mask=None, mask_scale=1.0
     ap, a_ld = _pm_operand(act, x, "stored activation", layout)
     dp, d_ld = _pm_operand(dres, x, "residual gradient", layout)
     r = _row_ptrs(coef)
+    t0 = _hbm_start()
     call("segk_bn_bwd_apply", _ptr(dz), _dt(dz), dz_ld, _ptr(x), _dt(x), x_ld, _ptr(dx), _dt(dx), dx_ld, layout, N,
          C, HW, r[0], r[1], r[2], r[3], 1 if relu else 0, _ptr(mask), ctypes.c_float(mask_scale), _ptr(gsums),
          1 if eval_mode else 0, ap, a_ld, dp, d_ld, _stream())
+    _hbm_stop("bn_bwd_apply", _nbytes(dz, x, dx, act, dres, mask), t0)
     return dx
 
 
