@@ -84,8 +84,16 @@ typedef struct {
   int out_dtype;
   const float* bias;      /* [Cout] or NULL (modeling/decoder.py:152-153, classifier) */
   const float* img_bias;  /* [N][Cout] or NULL: added to every pixel of image n */
-  double* stat_partials;  /* NULL, or [segk_conv_stat_rows(&a)][2][Cout] fp64: per-row-tile sum and
+  double* stat_partials;  /* NULL, or [batch][segk_conv_stat_rows(&a)][2][Cout] fp64: per-row-tile sum and
                              sum of squares of the UNBIASED output, for batch-norm statistics */
+  /* Several convolutions of the SAME input in one launch (the dilated ASPP branches, modeling/aspp.py:132-135):
+   * entry b uses weights w + b*w_batch (elements), dilation dil + b*dil_step and writes out + b*out_batch
+   * (elements; e.g. the next column slice of a concat buffer).  batch <= 1: a single convolution; biases must
+   * be NULL when batch > 1. */
+  int batch;
+  long long w_batch;
+  long long out_batch;
+  int dil_step;
 } segk_conv_args;
 
 /* nn.Conv2d forward (modeling/aspp.py:18, modeling/decoder.py:172,178) and, with transposed packed

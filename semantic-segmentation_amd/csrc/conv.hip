@@ -46,6 +46,8 @@ struct ConvDev {
   char* out;
   int out_ld;
   long long out_batch_b;
+  int dil_step;          // batch entry b convolves with dilation seg.dil + b * dil_step (the ASPP rate ladder)
+  long long stat_batch;  // doubles between the statistic partials of consecutive batch entries
   const float* bias;
   const float* img_bias;
   double* stat;
@@ -150,7 +152,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x4 (&acc)[G::
         double v = 0.0;
 #pragma unroll
         for (int w = 0; w < G::WPX; ++w) v += red[(w * 2 + which) * G::BCO + cl];
-        p.stat[((size_t)mt * 2 + which) * p.Cout + co] = v;
+        p.stat[bz * p.stat_batch + ((size_t)mt * 2 + which) * p.Cout + co] = v;
       }
     }
   }
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(G::THREADS, (G::THREADS == 256 && G::BCO == 256) ? 
   {
     unsigned long long mine = 0ull;
     for (int sg = 0; sg < p.nseg; ++sg) {
-      const int R = p.seg[sg].R, dil = p.seg[sg].dil;
+      const int R = p.seg[sg].R, dil = p.seg[sg].dil + (int)blockIdx.y * p.dil_step;
       for (int tap = 0; tap < R * R; ++tap) {
         const int dy = (tap / R - (R >> 1)) * dil, dx = (tap % R - (R >> 1)) * dil;
         bool any = false;
@@ -291,7 +293,8 @@ __global__ __launch_bounds__(G::THREADS, (G::THREADS == 256 && G::BCO == 256) ? 
       const SegDev& s = p.seg[sg];
       const int tap = taps_l[sg * 9 + ti];
       const int R = s.R;
-      const int dy = (tap / R - (R >> 1)) * s.dil, dx = (tap % R - (R >> 1)) * s.dil;
+      const int dil = s.dil + (int)bz * p.dil_step;
+      const int dy = (tap / R - (R >> 1)) * dil, dx = (tap % R - (R >> 1)) * dil;
       abase = s.w + bz * s.w_batch_b + (long long)tap * s.w_tap_b + (long long)co0 * s.w_ld_b + (long long)kc * BKB;
       bbase = s.in + bz * s.in_batch_b + (m0 + (long long)dy * p.W + dx) * s.in_ld_b + (long long)kc * BKB;
 #pragma unroll
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_pipe_kernel(const ConvDev p) 
   {
     unsigned long long mine = 0ull;
     for (int sg = 0; sg < p.nseg; ++sg) {
-      const int R = p.seg[sg].R, dil = p.seg[sg].dil;
+      const int R = p.seg[sg].R, dil = p.seg[sg].dil + (int)blockIdx.y * p.dil_step;
       for (int tap = 0; tap < R * R; ++tap) {
         const int dy = (tap / R - (R >> 1)) * dil, dx = (tap % R - (R >> 1)) * dil;
         bool any = false;
@@ -525,8 +528,9 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_pipe_kernel(const ConvDev p) 
       const SegDev& s = p.seg[l_sg];
       const int tap = taps_l[l_sg * 9 + l_ti];
       const int R = s.R;
-      l_dy = (tap / R - (R >> 1)) * s.dil;
-      l_dx = (tap % R - (R >> 1)) * s.dil;
+      const int dil = s.dil + (int)bz * p.dil_step;
+      l_dy = (tap / R - (R >> 1)) * dil;
+      l_dx = (tap % R - (R >> 1)) * dil;
       abase = s.w + bz * s.w_batch_b + (long long)tap * s.w_tap_b + (long long)co0 * s.w_ld_b + (long long)l_kc * BKB;
       bbase = s.in + bz * s.in_batch_b + ((ABL == 8 ? 1024 : m0) + (long long)l_dy * p.W + l_dx) * s.in_ld_b + (long long)l_kc * BKB;
     };
@@ -997,13 +1001,13 @@ static bool use_pipe() {
 }
 
 // Rows of statistic partials = pixel tiles of the geometry chosen for this problem.
-static bool use_big_tile(const ConvDev& d, bool wide) {
+static bool use_big_tile(const ConvDev& d, bool wide, int batch = 1) {
   // the big tile needs 128-byte K rows, full 256-channel tiles and enough tiles to fill 256 CUs twice
   if (!wide || d.Cout % TileBig::BCO != 0) return false;
   static const char* force = getenv("SEGK_CONV_TILE");  // experiments: "small" / "big"
   if (force && force[0] == 's') return false;
   if (force && (force[0] == 'b' || force[0] == 'h')) return true;
-  const long long tiles = ((d.M + TileBig::BPX - 1) / TileBig::BPX) * (d.Cout / TileBig::BCO);
+  const long long tiles = ((d.M + TileBig::BPX - 1) / TileBig::BPX) * (d.Cout / TileBig::BCO) * batch;
   return tiles >= 512;
 }
 
@@ -1049,13 +1053,16 @@ static bool fill_dev(const segk_conv_args* a, ConvDev& d) {
     d.seg[s].ck_b = g.Ck * es;
     d.seg[s].w_ld_b = g.Ck * es;
     d.seg[s].in_batch_b = 0;
-    d.seg[s].w_batch_b = 0;
+    d.seg[s].w_batch_b = (long long)a->w_batch * es;
     d.seg[s].w_tap_b = (long long)a->Cout * g.Ck * es;
     d.seg[s].R = g.R;
     d.seg[s].dil = g.dil;
     if (s < a->nseg && (d.seg[s].ck_b % 128) != 0) wide = false;
   }
-  d.out = (char*)a->out; d.out_ld = a->out_ld; d.out_batch_b = 0;
+  d.out = (char*)a->out; d.out_ld = a->out_ld;
+  d.out_batch_b = (long long)a->out_batch * dtype_size(a->out_dtype);
+  d.dil_step = a->dil_step;
+  d.stat_batch = 0;  // set once the tile geometry (= number of partial rows) is known
   d.bias = a->bias; d.img_bias = a->img_bias; d.stat = a->stat_partials;
   return wide;
 }
@@ -1065,7 +1072,7 @@ extern "C" int segk_conv_stat_rows(const segk_conv_args* a) {
     return SEGK_INVALID_ARG;
   ConvDev d;
   const bool wide = fill_dev(a, d);
-  return ceil_div(d.M, use_big_tile(d, wide) ? TileBig::BPX : TileSmall::BPX);
+  return ceil_div(d.M, use_big_tile(d, wide, a->batch > 1 ? a->batch : 1) ? TileBig::BPX : TileSmall::BPX);
 }
 
 extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
@@ -1073,7 +1080,11 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
   if (rc != SEGK_OK) return rc;
   ConvDev d;
   const bool wide = fill_dev(a, d);
-  const bool big = use_big_tile(d, wide);
+  const int batch = a->batch > 1 ? a->batch : 1;
+  SEGK_REQUIRE(batch <= 65535 && (batch == 1 || (!a->bias && !a->img_bias)),
+               "conv: batch=%d (biases are not batched)", batch);
+  const bool big = use_big_tile(d, wide, batch);
+  d.stat_batch = (long long)ceil_div(d.M, big ? TileBig::BPX : TileSmall::BPX) * 2 * d.Cout;
   hipStream_t st = (hipStream_t)stream;
   static const char* abl = getenv("SEGK_CONV_ABL");
   if (abl && abl[0] && big && use_pipe() && a->dtype == SEGK_BF16 && a->out_dtype == SEGK_BF16) {
@@ -1098,17 +1109,17 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
     return SEGK_OK;
   }
 #define SEGK_LAUNCH(T, TO)                                                          \
-  (big ? launch_fwd<T, 128, TO, TileBig>(d, st)                                     \
-       : (wide ? launch_fwd<T, 128, TO, TileSmall>(d, st) : launch_fwd<T, 64, TO, TileSmall>(d, st)))
+  (big ? launch_fwd<T, 128, TO, TileBig>(d, st, batch)                              \
+       : (wide ? launch_fwd<T, 128, TO, TileSmall>(d, st, batch) : launch_fwd<T, 64, TO, TileSmall>(d, st, batch)))
   if (a->dtype == SEGK_BF16 && big && use_pipe()) {
-    rc = a->out_dtype == SEGK_BF16 ? launch_pipe<bf16_t>(d, st) : launch_pipe<float>(d, st);
+    rc = a->out_dtype == SEGK_BF16 ? launch_pipe<bf16_t>(d, st, batch) : launch_pipe<float>(d, st, batch);
   } else if (a->dtype == SEGK_BF16) {
     rc = a->out_dtype == SEGK_BF16 ? SEGK_LAUNCH(bf16_t, bf16_t) : SEGK_LAUNCH(bf16_t, float);
   } else {
     // fp32 rows of 32 channels are always 128 bytes
     rc = a->out_dtype == SEGK_BF16
-             ? (big ? launch_fwd<float, 128, bf16_t, TileBig>(d, st) : launch_fwd<float, 128, bf16_t, TileSmall>(d, st))
-             : (big ? launch_fwd<float, 128, float, TileBig>(d, st) : launch_fwd<float, 128, float, TileSmall>(d, st));
+             ? (big ? launch_fwd<float, 128, bf16_t, TileBig>(d, st, batch) : launch_fwd<float, 128, bf16_t, TileSmall>(d, st, batch))
+             : (big ? launch_fwd<float, 128, float, TileBig>(d, st, batch) : launch_fwd<float, 128, float, TileSmall>(d, st, batch));
   }
 #undef SEGK_LAUNCH
   if (rc != SEGK_OK) return rc;
@@ -1190,6 +1201,7 @@ extern "C" int segk_gemm_nt(const segk_gemm_args* a, segk_stream_t stream) {
     if (s < a->nterms && (d.seg[s].ck_b % 128) != 0) wide = false;
   }
   d.out = (char*)a->C; d.out_ld = a->ldc; d.out_batch_b = a->c_batch * cs;
+  d.dil_step = 0; d.stat_batch = 0;
   d.bias = nullptr; d.img_bias = nullptr; d.stat = nullptr;
   const long long big_tiles = (long long)ceil_div(a->M, TileBig::BPX) * (a->N / TileBig::BCO) * a->batch;
   const bool big = wide && a->N % TileBig::BCO == 0 && big_tiles >= 512;

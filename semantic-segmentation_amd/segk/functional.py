@@ -154,12 +154,21 @@ def unit_forward(x, weight, R, dil, geom, spec, gamma, beta, out, relu=True, dro
     N, H, W = geom
     M = N * H * W
     Cout, Cin = weight.shape[0], weight.shape[1]
-    cd = x.dtype
-    wp = ops.pack_weight(weight.detach(), cd)
+    wp = ops.pack_weight(weight.detach(), x.dtype)
     # the pre-normalisation output stays fp32 (the accumulator's precision): statistics and the normalised
     # values then refer to the same numbers, and bf16 mode rounds once per layer instead of twice
     raw = torch.empty((M, Cout), dtype=torch.float32, device=x.device)
     stats = ops.conv_fwd([(x, wp, R, dil)], N, H, W, Cout, raw, want_stats=spec.training, true_ck=[Cin])
+    return unit_finish(x, raw, stats, weight, R, dil, geom, spec, gamma, beta, out, relu, drop_p, drop_training)
+
+
+def unit_finish(x, raw, stats, weight, R, dil, geom, spec, gamma, beta, out, relu=True, drop_p=0.0,
+                drop_training=True):
+    """Second half of a unit: batch-norm coefficients from the conv epilogue's statistic partials, then one fused
+    apply pass (BN, ReLU, dropout) from the fp32 conv output `raw` into `out`."""
+    N, H, W = geom
+    M = N * H * W
+    Cout, Cin = weight.shape[0], weight.shape[1]
     if spec.training:
         coef = _train_coeffs(stats, float(M), spec, gamma, beta)
     else:
@@ -262,11 +271,34 @@ class ASPPFunction(torch.autograd.Function):
         xp = _padded_input(to_pm(x, cd))
         cat = torch.empty((M, 5 * P), dtype=cd, device=x.device)
         recs = []
+        convs = [br.atrous_conv for br in branches]
+        dils = [c.dilation[0] for c in convs]
+        ladder = (all(c.kernel_size[0] == 3 and c.out_channels == P for c in convs[1:])
+                  and dils[2] - dils[1] == dils[3] - dils[2] and all(br.bn.training == branches[1].bn.training
+                                                                     for br in branches[1:]))
         for b, br in enumerate(branches):
+            if ladder and b >= 1:
+                break
             w, g, be = params[3 * b:3 * b + 3]
             conv = br.atrous_conv
             recs.append(unit_forward(xp, w, conv.kernel_size[0], conv.dilation[0], geom, _BNSpec(br.bn), g, be,
                                      cat[:, b * P:(b + 1) * P], relu=True))
+        if ladder:
+            # the three dilated 3x3 branches read the same input: one launch (three times the workgroups, which
+            # 274 tiles per branch need to fill 256 CUs), outputs side by side in one fp32 buffer
+            ws = [params[3 * b] for b in (1, 2, 3)]
+            Ck = ops.round_up(Cin, 32)
+            wp3 = torch.empty((3, 9, P, Ck), dtype=cd, device=x.device)
+            for i, w in enumerate(ws):
+                ops.pack_weight(w.detach(), cd, out=wp3[i])
+            raw3 = torch.empty((M, 3 * P), dtype=torch.float32, device=x.device)
+            training = branches[1].bn.training or branches[1].bn.running_mean is None
+            stats3 = ops.conv_fwd([(xp, wp3, 3, dils[1])], N, H, W, P, raw3[:, :P], want_stats=training,
+                                  true_ck=[Cin], batch=3, dil_step=dils[2] - dils[1], out_batch=P)
+            for i, b in enumerate((1, 2, 3)):
+                w, g, be = params[3 * b:3 * b + 3]
+                recs.append(unit_finish(xp, raw3[:, i * P:(i + 1) * P], stats3[i] if training else None, w, 3, dils[b],
+                                        geom, _BNSpec(branches[b].bn), g, be, cat[:, b * P:(b + 1) * P], relu=True))
         # image-pooling branch: mean over pixels -> 1x1 conv -> BN -> ReLU -> broadcast
         w, g, be = params[12:15]
         # (kept in fp32 whatever the compute dtype: N rows only, and its batch norm sees just N samples per

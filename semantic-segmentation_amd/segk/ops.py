@@ -126,8 +126,9 @@ def pm_to_nchw(src, N, H, W):
     return out
 
 
-def pack_weight(w, dtype, transpose=False):
-    """nn.Conv2d weight [Cout,Cin,R,R] fp32 -> [taps, rows, Ck] operand (see segk_pack_weight)."""
+def pack_weight(w, dtype, transpose=False, out=None):
+    """nn.Conv2d weight [Cout,Cin,R,R] fp32 -> [taps, rows, Ck] operand (see segk_pack_weight); `out` may be a
+    contiguous slice of a larger buffer of that shape."""
     _dev(w)
     if w.dtype != torch.float32:
         raise ValueError("master weights are float32")
@@ -136,18 +137,23 @@ def pack_weight(w, dtype, transpose=False):
     if R != S:
         raise ValueError("square kernels only")
     rows, k = (Cin, Cout) if transpose else (Cout, Cin)
-    out = torch.empty((R * R, rows, round_up(k, 32)), dtype=dtype, device=w.device)
+    shape = (R * R, rows, round_up(k, 32))
+    if out is None:
+        out = torch.empty(shape, dtype=dtype, device=w.device)
+    elif tuple(out.shape) != shape or out.dtype != dtype or not out.is_contiguous():
+        raise ValueError("pack_weight destination must be a contiguous %s tensor of shape %s" % (dtype, shape))
     call("segk_pack_weight", _ptr(w), _ptr(out), _dt(out), Cout, Cin, R, 1 if transpose else 0, _stream())
     return out
 
 
 # -------------------------------------------------------------------- conv ----
-def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=False, true_ck=None):
+def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=False, true_ck=None, batch=1,
+             dil_step=0, out_batch=0):
     """segs: list of (in_view [M, >=Ck], packed_w [taps, Cout, Ck], R, dil).  Writes `out` ([M, Cout'] view,
     Cout' >= Cout rounded up to 4).  Returns the [rows, 2, Cout] statistic partials when want_stats.
     true_ck: un-padded contracted channel counts per segment (only used for FLOP accounting)."""
     M = N * H * W
-    timer_ck = true_ck if true_ck is not None else [w.shape[2] for _, w, _, _ in segs]
+    timer_ck = true_ck if true_ck is not None else [w.shape[-1] for _, w, _, _ in segs]
     a = ConvArgs()
     a.N, a.H, a.W, a.Cout, a.nseg = N, H, W, Cout, len(segs)
     if not 1 <= len(segs) <= _lib.MAX_SEG:
@@ -158,13 +164,17 @@ def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=Fals
         ld, _ = _pm(x)
         if x.shape[0] != M:
             raise ValueError("segment %d has %d pixels, expected %d" % (i, x.shape[0], M))
-        if w.dim() != 3 or not w.is_contiguous() or w.shape[0] != R * R or w.shape[1] != Cout:
+        if batch > 1:
+            if w.dim() != 4 or not w.is_contiguous() or w.shape[0] != batch or w.shape[1] != R * R or w.shape[2] != Cout:
+                raise ValueError("segment %d: batched packed weight shape %s does not match batch=%d taps=%d Cout=%d"
+                                 % (i, tuple(w.shape), batch, R * R, Cout))
+        elif w.dim() != 3 or not w.is_contiguous() or w.shape[0] != R * R or w.shape[1] != Cout:
             raise ValueError("segment %d: packed weight shape %s does not match taps=%d Cout=%d"
                              % (i, tuple(w.shape), R * R, Cout))
         if x.dtype != w.dtype or (dt is not None and x.dtype != dt):
             raise ValueError("all conv operands share one dtype")
         dt = x.dtype
-        Ck = w.shape[2]
+        Ck = w.shape[-1]
         if x.shape[1] < Ck and ld < Ck:
             raise ValueError("segment %d: activation row has %d elements, weight contracts %d" % (i, ld, Ck))
         a.seg[i].inp, a.seg[i].w = x.data_ptr(), w.data_ptr()
@@ -180,10 +190,15 @@ def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=Fals
             raise ValueError("%s must be contiguous float32 with %d elements" % (name, n))
     a.bias = bias.data_ptr() if bias is not None else None
     a.img_bias = img_bias.data_ptr() if img_bias is not None else None
+    if batch > 1:
+        if len(segs) != 1 or bias is not None or img_bias is not None:
+            raise ValueError("a batched convolution has one segment and no bias")
+        a.batch, a.w_batch, a.out_batch, a.dil_step = batch, segs[0][1][0].numel(), out_batch, dil_step
     stats = None
     if want_stats:
         rows = call("segk_conv_stat_rows", ctypes.byref(a))
-        stats = torch.empty((rows, 2, Cout), dtype=torch.float64, device=out.device)
+        stats = torch.empty((rows, 2, Cout) if batch <= 1 else (batch, rows, 2, Cout), dtype=torch.float64,
+                            device=out.device)
         a.stat_partials = stats.data_ptr()
     else:
         a.stat_partials = None
@@ -191,7 +206,7 @@ def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=Fals
     call("segk_conv_fwd", ctypes.byref(a), _stream())
     if t0 is not None:
         # nominal FLOPs: every tap counted (also the ones that fall outside the image), padded channels not
-        fl = sum(2.0 * M * Cout * timer_ck[i] * segs[i][2] ** 2 for i in range(len(segs)))
+        fl = max(batch, 1) * sum(2.0 * M * Cout * timer_ck[i] * segs[i][2] ** 2 for i in range(len(segs)))
         TIMER.stop("conv_fwd_kernel", fl, t0)
     return stats
 
