@@ -70,6 +70,12 @@ struct Mma<float> {
   }
 };
 
+// pixel index within its image; 32-bit arithmetic whenever the global pixel index fits (a 64-bit modulo is ~50
+// instructions, and the weight-gradient loader needs one per row per chunk)
+__device__ __forceinline__ int pixel_in_image(long long m, int HW) {
+  return (m >> 31) == 0 ? (int)((unsigned)m % (unsigned)HW) : (int)(m % HW);
+}
+
 // byte offset of 16-byte chunk c of row r in a [128][BKB] tile
 template <int BKB>
 __device__ __forceinline__ int tile_off(int r, int c) {
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(G::THREADS, (G::THREADS == 256 && G::BCO == 256) ? 
     rvalid[i] = m < p.M;
     const long long mm = rvalid[i] ? m : 0;
     rm[i] = mm;
-    const int rem = (int)(mm % p.HW);
+    const int rem = pixel_in_image(mm, p.HW);
     ry[i] = rem / p.W;
     rx[i] = rem - ry[i] * p.W;
   }
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_pipe_kernel(const ConvDev p) 
       b_pix[h][i] = (rr >> 5) * 64 + h * 32 + (rr & 31);
       const long long m = m0 + b_pix[h][i];
       b_in[h][i] = m < p.M;
-      const int rem = (int)((b_in[h][i] ? m : 0) % p.HW);
+      const int rem = pixel_in_image(b_in[h][i] ? m : 0, p.HW);
       b_y[h][i] = rem / p.W;
       b_x[h][i] = rem - b_y[h][i] * p.W;
     }
@@ -842,7 +848,7 @@ __global__ __launch_bounds__(CONV_THREADS * NSUB, NSUB == 1 ? 2 : 1) void conv_w
       rd[i] = z;
       rx[i] = z;
       if (m < pend) {
-        const int rem = (int)(m % p.HW);
+        const int rem = pixel_in_image(m, p.HW);
         const int y = rem / p.W, x = rem - y * p.W;
         const bool in_img = (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W;
         if (in_img) {
