@@ -37,10 +37,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
-    ap.add_argument("--size", type=int, default=513)
-    ap.add_argument("--classes", type=int, default=21)
-    ap.add_argument("--out-stride", type=int, default=16)
+    ap.add_argument("--config", choices=["A", "D", "E"], default="A",
+                    help="A (default, the headline workload): OS16 513x513 K=21 batch 16; D: OS8 769x769 K=19 batch 4; "
+                         "E: dual-attention DeepLab, 513x513 K=81 batch 32.  D and E are parity-test shapes; their "
+                         "bench lines are informative only.  --batch/--size/--classes/--out-stride override.")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU")
+    ap.add_argument("--size", type=int, default=None)
+    ap.add_argument("--classes", type=int, default=None)
+    ap.add_argument("--out-stride", type=int, default=None)
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--feeder-fp32", action="store_true", help="run the PyTorch feeder in fp32 even in bf16 mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -54,7 +58,12 @@ def parse():
                     help="SynchronizedBatchNorm2d (HIP) in every layer, the reference's --sync-bn (train.py:321-322); "
                          "auto = only with more than one rank, its default when the flag is not given "
                          "(train.py:381-385); off = torch's nn.BatchNorm2d (MIOpen) in the feeder")
-    return ap.parse_args()
+    args = ap.parse_args()
+    preset = {"A": (16, 513, 21, 16), "D": (4, 769, 19, 8), "E": (32, 513, 81, 16)}[args.config]
+    for name, v in zip(("batch", "size", "classes", "out_stride"), preset):
+        if getattr(args, name) is None:
+            setattr(args, name, v)
+    return args
 
 
 def synthetic_batch(batch, size, classes, device, seed):
@@ -121,6 +130,7 @@ def main():
     args = parse()
     from segk import config, ops, parallel
     from segk.modeling.deeplab import DeepLab
+    from segk.modeling.deeplab_damm import DeepLab as DeepLabDAMM
     from segk.utils.loss import SegmentationLosses
     from segk.utils.lr_scheduler import LR_Scheduler
 
@@ -137,7 +147,13 @@ def main():
     torch.backends.cudnn.benchmark = not args.no_miopen_benchmark
     torch.manual_seed(1)  # the reference's --seed default; identical initial weights on every rank
     sync_bn = (world > 1) if args.sync_bn == "auto" else (args.sync_bn == "on")
-    model = DeepLab(backbone="resnet", output_stride=args.out_stride, num_classes=args.classes, sync_bn=sync_bn).to(dev)
+    ctor = DeepLabDAMM if args.config == "E" else DeepLab
+    model = ctor(backbone="resnet", output_stride=args.out_stride, num_classes=args.classes, sync_bn=sync_bn).to(dev)
+    if args.config == "E":
+        # the reference initialises both attention gammas to 0 (identity branch); give them the value a trained
+        # model would have so the attention products are not multiplied by zero
+        for m in (model.damm.damm1, model.damm.damm2):
+            m.gamma.data.fill_(0.5)
     model.train()
     if feeder_amp:
         fmt = torch.contiguous_format if args.feeder_nchw else torch.channels_last
@@ -201,14 +217,15 @@ def main():
     if rank == 0:
         images = world * args.batch * args.steps
         line = {
-            "metric": "train images/sec @513x513 DeepLabv3+ OS16",
+            "metric": "train images/sec @%dx%d DeepLabv3+ OS%d" % (args.size, args.size, args.out_stride),
             "value": images / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "DeepLabv3+ ResNet-101 OS%d, %d classes, %dx%d, batch %d/GPU: full train step "
+            "config": {"workload": "DeepLabv3+ %sResNet-101 OS%d, %d classes, %dx%d, batch %d/GPU: full train step "
                                    "(feeder convolutions on PyTorch-ROCm %s, batch norm %s, head on HIP kernels %s, "
                                    "CE ignore 255, SGD)"
-                                   % (args.out_stride, args.classes, args.size, args.size, args.batch,
+                                   % ("+ dual attention (DAMM) " if args.config == "E" else "", args.out_stride,
+                                      args.classes, args.size, args.size, args.batch,
                                       "bf16 autocast channels_last" if feeder_amp else "fp32",
                                       "HIP SynchronizedBatchNorm2d in all layers" if sync_bn else "nn.BatchNorm2d (MIOpen)",
                                       args.dtype),
@@ -246,7 +263,7 @@ def main():
                                                   "norm, %d launches of one extra step after the timed region; algorithmic bytes = every "
                                                   "operand tensor once)" % sum(v["launches"] for v in bn),
                                         "share_of_step": ms / (1000.0 * elapsed / args.steps)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "A":
             del model, opt, buckets
             torch.cuda.empty_cache()
             line["cpu_baseline"] = cpu_baseline(args)
