@@ -3,6 +3,7 @@
 // Statistics are produced as per-block partial rows that a second kernel sums in index order, so the
 // result does not depend on scheduling (no float atomics).
 #include <algorithm>
+#include <cstdlib>
 #include <initializer_list>
 #include <utility>
 
@@ -92,9 +93,11 @@ template <>
 __device__ __forceinline__ void load_mask<1>(const uint8_t* p, float (&v)[1]) { v[0] = (float)*p; }
 
 // ---------------------------------------------------------------------------------------------
-// Pixel-major kernels.  A block owns a contiguous pixel range (blockIdx.x) and a slab of up to
-// BN_THREADS*VEC channels (blockIdx.y).  Thread t owns channel group (t % cg) and walks the pixels
-// (t / cg) + k*rpb, four at a time so that several 16-byte loads are in flight per lane.
+// Pixel-major kernels.  A block owns a contiguous pixel range (blockIdx.x) and a slab of channels
+// (blockIdx.y): up to BN_THREADS*VEC of them in the elementwise kernels, 64 (one 128-byte line of bf16
+// per pixel) in the statistics kernels, whose partial rows then stay few however the chip is filled.
+// Thread t owns channel group (t % cg) and walks the pixels (t / cg) + k*rpb, four at a time so that
+// several 16-byte loads are in flight per lane.
 // ---------------------------------------------------------------------------------------------
 struct PmThread {
   int c_base, Cs, cg, rpb, cgi, pr;
@@ -103,9 +106,8 @@ struct PmThread {
 };
 
 template <int VEC>
-__device__ __forceinline__ PmThread pm_thread(int C, long long M) {
+__device__ __forceinline__ PmThread pm_thread(int C, long long M, int slab = BN_THREADS * VEC) {
   PmThread t;
-  const int slab = BN_THREADS * VEC;
   t.c_base = blockIdx.y * slab;
   t.Cs = C - t.c_base < slab ? C - t.c_base : slab;
   t.cg = t.Cs / VEC;
@@ -142,8 +144,8 @@ __device__ __forceinline__ void block_reduce_pm(ACC (&a)[VEC], ACC (&b)[VEC], co
 
 template <typename TX, int VEC>
 __global__ __launch_bounds__(BN_THREADS) void bn_stats_pm_kernel(const TX* __restrict__ x, int ld, long long M, int C,
-                                                                  double* __restrict__ partials) {
-  const PmThread t = pm_thread<VEC>(C, M);
+                                                                  int slab, double* __restrict__ partials) {
+  const PmThread t = pm_thread<VEC>(C, M, slab);
   // fp64 accumulation: squares of fp32 values are exact in fp64, so E[x^2] - E[x]^2 loses nothing
   double a[VEC], b[VEC];
 #pragma unroll
@@ -205,8 +207,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_pm_kernel(
     const TG* __restrict__ dz, int dz_ld, const TX* __restrict__ x, int x_ld, long long M, int C,
     const float* __restrict__ mean, const float* __restrict__ inv_std, const float* __restrict__ scale,
     const float* __restrict__ shift, int relu, const uint8_t* __restrict__ mask, float mask_scale,
-    const TG* __restrict__ act, int act_ld, double* __restrict__ partials) {
-  const PmThread t = pm_thread<VEC>(C, M);
+    const TG* __restrict__ act, int act_ld, int slab, double* __restrict__ partials) {
+  const PmThread t = pm_thread<VEC>(C, M, slab);
   extern __shared__ float cf[];  // [4][Cs]: mean, inv_std, scale, shift of the slab, loaded once per workgroup
   for (int i = threadIdx.x; i < t.Cs; i += BN_THREADS) {
     const int c = t.c_base + i;
@@ -576,14 +578,27 @@ __global__ void bn_coeffs_eval_kernel(const float* __restrict__ running_mean, co
 
 static bool aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 
-// partial rows (= pixel ranges = grid.x) of the pixel-major statistics kernels
+// channels per workgroup (grid.y slabs) of the pixel-major statistics kernels
+static int pm_stat_slab(int C) { return C > 64 ? 64 : C; }
+
+static int pm_stat_blocks() {
+  static const int blocks = [] {
+    const char* e = getenv("SEGK_BN_STAT_BLOCKS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 512;
+  }();
+  return blocks;
+}
+
+// partial rows (= pixel ranges = grid.x) of the pixel-major statistics kernels: about pm_stat_blocks() workgroups
+// over rows x slabs, at least 64 pixels per row
 static int pm_rows(long long M, int C) {
-  long long cap = 524288 / (C > 0 ? C : 1);
-  if (cap < 64) cap = 64;
-  if (cap > BN_MAX_ROWS_PM) cap = BN_MAX_ROWS_PM;
-  long long r = (M + 63) / 64;
+  const int slabs = ceil_div(C, pm_stat_slab(C));
+  long long r = ceil_div(pm_stat_blocks(), slabs);
+  const long long by_pixels = (M + 63) / 64;
+  if (r > by_pixels) r = by_pixels;
+  if (r > BN_MAX_ROWS_PM) r = BN_MAX_ROWS_PM;
   if (r < 1) r = 1;
-  if (r > cap) r = cap;
   return (int)r;
 }
 
@@ -662,8 +677,9 @@ extern "C" int segk_bn_stats(const void* x, int dtype, int layout, int N, int C,
     const long long M = (long long)N * HW;
     const int rows = pm_rows(M, C);
     const int vec = pm_vec(C, {ld}, {{x, dtype}}, nullptr);
-    SEGK_DISPATCH_DTYPE(dtype, T, SEGK_DISPATCH_VEC(vec, V, (bn_stats_pm_kernel<T, V><<<dim3(rows, ceil_div(C, BN_THREADS * V)), BN_THREADS, 0, st>>>(
-        (const T*)x, ld, M, C, partials))));
+    const int slab = pm_stat_slab(C);
+    SEGK_DISPATCH_DTYPE(dtype, T, SEGK_DISPATCH_VEC(vec, V, (bn_stats_pm_kernel<T, V><<<dim3(rows, ceil_div(C, slab)), BN_THREADS, 0, st>>>(
+        (const T*)x, ld, M, C, slab, partials))));
   } else {
     SEGK_REQUIRE(C <= 2147483647, "bn_stats: C too large");
     dim3 grid(C, nchw_rows(N, HW));
@@ -774,18 +790,19 @@ extern "C" int segk_bn_bwd_stats(const void* dz, int dz_dtype, int dz_ld, const 
     const int rows = pm_rows(M, C);
     const int vec = act ? pm_vec(C, {x_ld, dz_ld, act_ld}, {{x, x_dtype}, {dz, dz_dtype}, {act, dz_dtype}}, mask)
                         : pm_vec(C, {x_ld, dz_ld}, {{x, x_dtype}, {dz, dz_dtype}}, mask);
-    const size_t lds = (size_t)4 * (C < BN_THREADS * vec ? C : BN_THREADS * vec) * sizeof(float);
+    const int slab = pm_stat_slab(C);
+    const size_t lds = (size_t)4 * slab * sizeof(float);
 #define LAUNCH_BS(TG, TX)                                                                                           \
   SEGK_DISPATCH_VEC(vec, V, {                                                                                       \
-    const dim3 grid_(rows, ceil_div(C, BN_THREADS * V));                                                            \
+    const dim3 grid_(rows, ceil_div(C, slab));                                                                      \
     if (act)                                                                                                        \
       bn_bwd_stats_pm_kernel<TG, TX, V, true><<<grid_, BN_THREADS, lds, st>>>(                                      \
           (const TG*)dz, dz_ld, (const TX*)x, x_ld, M, C, mean, inv_std, scale, shift, relu, mask, mask_scale,      \
-          (const TG*)act, act_ld, partials);                                                                        \
+          (const TG*)act, act_ld, slab, partials);                                                                  \
     else                                                                                                            \
       bn_bwd_stats_pm_kernel<TG, TX, V, false><<<grid_, BN_THREADS, lds, st>>>(                                     \
           (const TG*)dz, dz_ld, (const TX*)x, x_ld, M, C, mean, inv_std, scale, shift, relu, mask, mask_scale,      \
-          nullptr, 0, partials);                                                                                    \
+          nullptr, 0, slab, partials);                                                                              \
   })
     if (dz_dtype == SEGK_BF16 && x_dtype == SEGK_BF16) { LAUNCH_BS(bf16_t, bf16_t); }
     else if (dz_dtype == SEGK_BF16) { LAUNCH_BS(bf16_t, float); }
