@@ -17,6 +17,7 @@
 //   order, so results are reproducible: no float atomics).
 #include <stdlib.h>
 
+#include <cstdio>
 #include "common.h"
 
 namespace segk {
@@ -111,15 +112,32 @@ struct TileCfg {
 typedef TileCfg<128, 128, 2, 2> TileSmall;
 typedef TileCfg<256, 256, 4, 2> TileBig;
 
+// Sum of a double over the 16 lanes of a DPP row, result in every lane: two quad permutes, then the half-row and the
+// row mirror (VALU only; a 64-bit __shfl_xor goes through the LDS crossbar twice per step).
+template <int CTRL>
+__device__ __forceinline__ double dpp_add_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v) {
+  v = dpp_add_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add_f64<0x141>(v);  // row_half_mirror
+  v = dpp_add_f64<0x140>(v);  // row_mirror
+  return v;
+}
+
 // Epilogue shared by the forward kernels: optional fp64 batch-norm statistics of the unbiased accumulators, then
 // bias / per-image bias and the store.  acc[i][j][r] = out[pixel = wc*MJ*16 + j*16 + (lane&15)]
 //                                                         [co = wr*MI*16 + i*16 + (lane>>4)*4 + r]
-template <typename TO, typename G>
+template <typename TO, typename G, int ABL = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x4 (&acc)[G::MI][G::MJ], char* smem, int wr, int wc,
                                               int lane, int tid, int co0, long long m0, long long mt, long long bz) {
   constexpr int MI = G::MI, MJ = G::MJ, NT = G::THREADS;
   const int fq = lane >> 4, fr = lane & 15;
-  if (p.stat) {
+  // timing ablations 5 (no output stores) and 6 (no statistics either): p.M < 0 is never true, the code stays live
+  if (p.stat && !(ABL == 6 && p.M >= 0)) {
     // fp64 sums: the squares of the fp32 accumulators are exact in fp64
     double* red = reinterpret_cast<double*>(smem);  // [WPX pixel parts][2][BCO]
 #pragma unroll
@@ -135,11 +153,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x4 (&acc)[G::
           s[r] += v;
           q[r] = fma(v, v, q[r]);
         }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          s[r] += __shfl_xor(s[r], o, 64);
-          q[r] += __shfl_xor(q[r], o, 64);
-        }
+        s[r] = row16_sum(s[r]);
+        q[r] = row16_sum(q[r]);
       }
       if (fr == 0) {
 #pragma unroll
@@ -164,6 +179,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x4 (&acc)[G::
   }
 
   const int cpad = (p.Cout + 3) & ~3;
+  if ((ABL == 5 || ABL == 6) && p.M >= 0) return;
 #pragma unroll
   for (int j = 0; j < MJ; ++j) {
     const long long m = m0 + wc * (MJ * 16) + j * 16 + fr;
@@ -386,7 +402,7 @@ __global__ __launch_bounds__(G::THREADS, (G::THREADS == 256 && G::BCO == 256) ? 
     }
   }
 
-  conv_epilogue<TO, G>(p, acc, smem, wr, wc, lane, tid, co0, m0, mt, bz);
+  conv_epilogue<TO, G, ABL>(p, acc, smem, wr, wc, lane, tid, co0, m0, mt, bz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1109,6 +1125,8 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
   if (abl && abl[0] && big && a->dtype == SEGK_BF16 && a->out_dtype == SEGK_BF16) {
     rc = abl[0] == '1' ? launch_fwd<bf16_t, 128, bf16_t, TileBig, 1>(d, st)
        : abl[0] == '2' ? launch_fwd<bf16_t, 128, bf16_t, TileBig, 2>(d, st)
+       : abl[0] == '5' ? launch_fwd<bf16_t, 128, bf16_t, TileBig, 5>(d, st)
+       : abl[0] == '6' ? launch_fwd<bf16_t, 128, bf16_t, TileBig, 6>(d, st)
                        : launch_fwd<bf16_t, 128, bf16_t, TileBig, 3>(d, st);
     if (rc != SEGK_OK) return rc;
     SEGK_CHECK_LAUNCH("conv_fwd");
