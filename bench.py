@@ -54,6 +54,9 @@ def parse():
                     help="leave torch.backends.cudnn.benchmark off (MIOpen then picks the feeder's conv algorithms "
                          "heuristically instead of timing them in the first step)")
     ap.add_argument("--feeder-nchw", action="store_true", help="keep the feeder in NCHW memory format")
+    ap.add_argument("--optimizer", choices=["hip", "torch"], default="hip",
+                    help="hip: segk.optim.SGD (one launch per parameter group; the bf16 feeder's convolution weights "
+                         "are held in bf16 with fp32 masters in the optimizer); torch: torch.optim.SGD on fp32 weights")
     ap.add_argument("--sync-bn", choices=["auto", "on", "off"], default="on",
                     help="SynchronizedBatchNorm2d (HIP) in every layer, the reference's --sync-bn (train.py:321-322); "
                          "auto = only with more than one rank, its default when the flag is not given "
@@ -164,9 +167,14 @@ def main():
             with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
                 return feeder_fwd(x.contiguous(memory_format=fmt))
         model.backbone.forward = amp_forward
-    opt = torch.optim.SGD([{"params": model.get_1x_lr_params(), "lr": 0.007},
-                           {"params": model.get_10x_lr_params(), "lr": 0.07}],
-                          momentum=0.9, weight_decay=5e-4, nesterov=False)
+    groups = [{"params": list(model.get_1x_lr_params()), "lr": 0.007},
+              {"params": list(model.get_10x_lr_params()), "lr": 0.07}]
+    if args.optimizer == "hip":
+        from segk.optim import SGD
+        low = [m.weight for m in model.backbone.modules() if isinstance(m, torch.nn.Conv2d)] if feeder_amp else []
+        opt = SGD(groups, momentum=0.9, weight_decay=5e-4, nesterov=False, low_precision=low)
+    else:
+        opt = torch.optim.SGD(groups, momentum=0.9, weight_decay=5e-4, nesterov=False)
     criterion = SegmentationLosses(weight=None, cuda=True).build_loss("ce")
     scheduler = LR_Scheduler("poly", 0.007, 50, 1000, quiet=True)
     buckets = parallel.GradientBuckets([p for g in opt.param_groups for p in g["params"]])
@@ -223,12 +231,13 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "DeepLabv3+ %sResNet-101 OS%d, %d classes, %dx%d, batch %d/GPU: full train step "
                                    "(feeder convolutions on PyTorch-ROCm %s, batch norm %s, head on HIP kernels %s, "
-                                   "CE ignore 255, SGD)"
+                                   "CE ignore 255, %s)"
                                    % ("+ dual attention (DAMM) " if args.config == "E" else "", args.out_stride,
                                       args.classes, args.size, args.size, args.batch,
                                       "bf16 autocast channels_last" if feeder_amp else "fp32",
                                       "HIP SynchronizedBatchNorm2d in all layers" if sync_bn else "nn.BatchNorm2d (MIOpen)",
-                                      args.dtype),
+                                      args.dtype,
+                                      "HIP SGD, fp32 master weights" if args.optimizer == "hip" else "torch SGD"),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "final_loss": final_loss},
         }

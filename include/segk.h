@@ -296,6 +296,25 @@ int segk_argmax(const float* logits, int N, int K, int HW, int64_t* pred, segk_s
 int segk_confmat(const void* gt, int gt_is_i64, const int64_t* pred, long long count, int K, int64_t* cm,
                  segk_stream_t stream);
 
+/* ---- optimizer ------------------------------------------------------------------------------ */
+/* torch.optim.SGD(momentum, weight_decay, dampening 0, nesterov off) as the trainers build it (train.py:56-61),
+ * over many tensors in one launch.  The caller cuts each tensor into chunks (any size; 64 Ki elements is a good one)
+ * and passes a device table with one entry per chunk:
+ *   d = grad + weight_decay * master;  momentum_buf = momentum * momentum_buf + d;  master -= lr * momentum_buf
+ * (a zero-initialised buffer reproduces torch's first step, which copies d).  dtype is the type of param and
+ * grad: for SEGK_F32, master must be the parameter itself; for SEGK_BF16, master is its fp32 copy and param
+ * receives the rounded result. */
+typedef struct {
+  void* param;
+  const void* grad;
+  float* momentum;
+  float* master;
+  int n;
+  int dtype;
+} segk_sgd_chunk;
+int segk_sgd_step(const segk_sgd_chunk* table, int n_chunks, float lr, float momentum, float weight_decay,
+                  segk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,3 +124,14 @@ def predict(logits):
 def poly_lr(base_lr, it, total_iters, power=0.9):
     """lr_scheduler.py:50."""
     return base_lr * pow((1 - 1.0 * it / total_iters), power)
+
+
+# ------------------------------------------------------------------- SGD ----
+def sgd_step(w, g, buf, lr, momentum=0.9, weight_decay=5e-4):
+    """One update of torch.optim.SGD as train.py:56-61 configures it (dampening 0, nesterov off), fp32 numpy:
+    d = g + wd*w; buf = momentum*buf + d (a zero buffer gives torch's first step, buf = d); w = w - lr*buf.
+    Returns (w, buf)."""
+    w, g, buf = (np.asarray(a, dtype=np.float32) for a in (w, g, buf))
+    d = g + np.float32(weight_decay) * w
+    buf = np.float32(momentum) * buf + d
+    return w - np.float32(lr) * buf, buf

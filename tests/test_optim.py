@@ -1,0 +1,91 @@
+"""Device SGD (segk.optim.SGD) against torch.optim.SGD and the oracle restatement."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops_ref
+
+
+def test_oracle_sgd_matches_torch_cpu():
+    rng = np.random.default_rng(3)
+    w0 = rng.standard_normal(1000).astype(np.float32)
+    p = torch.nn.Parameter(torch.from_numpy(w0.copy()))
+    opt = torch.optim.SGD([p], lr=0.05, momentum=0.9, weight_decay=5e-4)
+    w, buf = w0.copy(), np.zeros_like(w0)
+    for it in range(4):
+        g = rng.standard_normal(1000).astype(np.float32)
+        opt.param_groups[0]["lr"] = ops_ref.poly_lr(0.05, it, 10)
+        p.grad = torch.from_numpy(g.copy())
+        opt.step()
+        w, buf = ops_ref.sgd_step(w, g, buf, ops_ref.poly_lr(0.05, it, 10))
+        np.testing.assert_allclose(w, p.detach().numpy(), rtol=2e-6, atol=1e-7)
+
+
+SHAPES = [(7,), (1,), (65536 + 3,), (256, 48, 3, 3), (21, 256, 1, 1), (3, 70001)]
+
+
+def _grads(shapes, seed, dev, dtype=torch.float32):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return [torch.randn(s, generator=g).to(dev).to(dtype) for s in shapes]
+
+
+@pytest.mark.gpu
+def test_sgd_fp32_matches_torch():
+    from segk.optim import SGD
+    dev = "cuda"
+    init = _grads(SHAPES, 0, dev)
+    mine = [torch.nn.Parameter(t.clone()) for t in init]
+    ref = [torch.nn.Parameter(t.clone()) for t in init]
+    # one convolution weight in channels_last, as the feeder holds them
+    mine[3].data = mine[3].data.contiguous(memory_format=torch.channels_last)
+    skip = 4  # this parameter never receives a gradient
+    o1 = SGD([{"params": mine[:3], "lr": 0.007}, {"params": mine[3:], "lr": 0.07}], momentum=0.9, weight_decay=5e-4)
+    o2 = torch.optim.SGD([{"params": ref[:3], "lr": 0.007}, {"params": ref[3:], "lr": 0.07}], momentum=0.9,
+                         weight_decay=5e-4)
+    for it in range(4):
+        lr = ops_ref.poly_lr(0.007, it, 10)
+        for o in (o1, o2):
+            o.param_groups[0]["lr"] = lr
+            o.param_groups[1]["lr"] = 10 * lr
+            o.zero_grad(set_to_none=True)
+        gs = _grads(SHAPES, 10 + it, dev)
+        for k, (a, b, g) in enumerate(zip(mine, ref, gs)):
+            if k == skip:
+                continue
+            b.grad = g.clone()
+            a.grad = g.clone().contiguous(memory_format=torch.channels_last) if k == 3 else g.clone()
+        o1.step()
+        o2.step()
+    torch.cuda.synchronize()
+    for k, (a, b) in enumerate(zip(mine, ref)):
+        torch.testing.assert_close(a.detach().contiguous(), b.detach(), rtol=2e-6, atol=1e-7)
+    assert torch.equal(mine[skip].detach(), init[skip])
+
+
+@pytest.mark.gpu
+def test_sgd_bf16_parameters_keep_fp32_master():
+    from segk.optim import SGD
+    dev = "cuda"
+    init = _grads(SHAPES, 1, dev)
+    mine = [torch.nn.Parameter(t.clone()) for t in init]
+    ref = [torch.nn.Parameter(t.clone()) for t in init]
+    o1 = SGD(mine, lr=0.05, momentum=0.9, weight_decay=5e-4, low_precision=mine)
+    o2 = torch.optim.SGD(ref, lr=0.05, momentum=0.9, weight_decay=5e-4)
+    assert all(p.dtype == torch.bfloat16 for p in mine)
+    for it in range(3):
+        gs = _grads(SHAPES, 20 + it, dev, torch.bfloat16)
+        for a, b, g in zip(mine, ref, gs):
+            a.grad = g.clone()
+            b.grad = g.float()
+        o1.step()
+        o2.step()
+    torch.cuda.synchronize()
+    for a, b in zip(mine, ref):
+        master = o1.state[a]["master"].reshape(a.shape)
+        torch.testing.assert_close(master, b.detach(), rtol=2e-6, atol=1e-7)
+        assert torch.equal(a.detach(), master.to(torch.bfloat16))   # the bf16 copy is the rounded master
+
+    lin = torch.nn.Linear(4, 4, bias=False).to(dev)
+    o3 = SGD(lin.parameters(), lr=0.1, low_precision=[lin.weight])
+    sd = o3.full_precision_state_dict(lin)
+    assert sd["weight"].dtype == torch.float32 and lin.weight.dtype == torch.bfloat16
