@@ -54,6 +54,9 @@ def parse():
                     help="leave torch.backends.cudnn.benchmark off (MIOpen then picks the feeder's conv algorithms "
                          "heuristically instead of timing them in the first step)")
     ap.add_argument("--feeder-nchw", action="store_true", help="keep the feeder in NCHW memory format")
+    ap.add_argument("--fused-loss", action="store_true",
+                    help="model.forward_loss: final upsample fused into the cross entropy (opt-in API; the default "
+                         "step materialises the full-size logits like the reference's trainer)")
     ap.add_argument("--optimizer", choices=["hip", "torch"], default="hip",
                     help="hip: segk.optim.SGD (one launch per parameter group; the bf16 feeder's convolution weights "
                          "are held in bf16 with fp32 masters in the optimizer); torch: torch.optim.SGD on fp32 weights")
@@ -183,8 +186,11 @@ def main():
     def step(i):
         scheduler(opt, i, 0, 0.0)
         opt.zero_grad(set_to_none=True)
-        out = model(image)
-        loss = criterion(out, target)
+        if args.fused_loss:
+            loss = model.forward_loss(image, target)
+        else:
+            out = model(image)
+            loss = criterion(out, target)
         loss.backward()
         buckets.reduce()
         opt.step()

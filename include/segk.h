@@ -287,6 +287,20 @@ int segk_ce_partial_rows(long long pixels);
 int segk_ce_bwd(const float* logits, const float* target, const float* weight, const float* lse, int N, int K,
                 int HW, int ignore_index, const float* coef_dev, float* dlogits, segk_stream_t stream);
 
+/* Final upsample (modeling/deeplab.py:252) fused with the cross entropy (utils/loss.py:23-35): the loss of
+ * F.interpolate(low, (Ho,Wo), bilinear, align_corners=True) without writing the full-resolution logits.
+ * low: pixel-major fp32 [N*Hi*Wi][low_ld], K classes; target fp32 [N][Ho][Wo]; lse, partials, sums as segk_ce_fwd
+ * (partials: segk_ce_partial_rows(N*Ho*Wo) rows of 2 floats). */
+int segk_upsample_ce_fwd(const float* low, int low_ld, int N, int K, int Hi, int Wi, const float* target,
+                         const float* weight, int Ho, int Wo, int ignore_index, float* lse, float* partials,
+                         float* sums, segk_stream_t stream);
+/* Its gradient with respect to low: dlow pixel-major fp32 [N*Hi*Wi][dlow_ld], channels K..dlow_cpad zero-filled.
+ * workspace: segk_upsample_bwd_workspace(SEGK_NCHW, N, K, Ho, Wi) floats; coef_dev as segk_ce_bwd. */
+int segk_upsample_ce_bwd(const float* low, int low_ld, int N, int K, int Hi, int Wi, const float* target,
+                         const float* weight, const float* lse, int Ho, int Wo, int ignore_index,
+                         const float* coef_dev, float* workspace, float* dlow, int dlow_ld, int dlow_cpad,
+                         segk_stream_t stream);
+
 /* ---- evaluator ------------------------------------------------------------------------------ */
 /* np.argmax(logits, axis=1) (train.py:217): first maximal index, NaN counts as maximal. */
 int segk_argmax(const float* logits, int N, int K, int HW, int64_t* pred, segk_stream_t stream);

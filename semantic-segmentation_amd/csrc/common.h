@@ -36,6 +36,10 @@ void set_error(const char* fmt, ...);
     }                                                                                \
   } while (0)
 
+// loss.hip: rows of {sum w*nll, sum w} partials for `pixels` pixels, and their fixed-order fp64 sum -> sums[2]
+int ce_partial_rows(long long pixels);
+int launch_ce_finish(const float* partials, int rows, float* sums, hipStream_t st);
+
 static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 static inline bool valid_dtype(int d) { return d == SEGK_F32 || d == SEGK_BF16; }

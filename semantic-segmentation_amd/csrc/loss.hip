@@ -173,6 +173,15 @@ __global__ __launch_bounds__(256) void confmat_kernel(const void* __restrict__ g
   }
 }
 
+
+
+int ce_partial_rows(long long pixels) { return ce_rows(pixels); }
+int launch_ce_finish(const float* partials, int rows, float* sums, hipStream_t st) {
+  ce_finish_kernel<<<1, 256, 0, st>>>(partials, rows, sums);
+  SEGK_CHECK_LAUNCH("ce_finish");
+  return SEGK_OK;
+}
+
 }  // namespace segk
 
 using namespace segk;

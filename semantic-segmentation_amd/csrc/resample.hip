@@ -337,6 +337,158 @@ __global__ __launch_bounds__(256) void upsample_bwd_cols_kernel(const float* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Final upsample fused with the cross entropy: the full-resolution logits are never written.
+//   forward : thread per output pixel interpolates its K logits from the four source pixels (pixel-major fp32,
+//             cache resident: 2 MB per image), log-sum-exp on the fly, NLL of the label.
+//   backward: the separable upsample gradient with its first pass computing
+//             g[k][ox] = coef * w_t * (exp(logit_k - lse) - [k == t]) instead of loading it.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ce_label_of(float t) { return (int)(long long)t; }  // .long(): truncation
+
+__device__ __forceinline__ float lerp4(const Tap& ty, const Tap& tx, float a, float b, float c, float d) {
+  return ty.w0 * (tx.w0 * a + tx.w1 * b) + ty.w1 * (tx.w0 * c + tx.w1 * d);
+}
+
+__global__ __launch_bounds__(256) void upsample_ce_fwd_kernel(const float* __restrict__ low, int ld, int K, int Hi, int Wi,
+                                                              const float* __restrict__ target,
+                                                              const float* __restrict__ weight, int Ho, int Wo,
+                                                              long long P, float sy, float sx, int ignore_index,
+                                                              float* __restrict__ lse_out, float* __restrict__ partials) {
+  float loss = 0.f, wsum = 0.f;
+  const int HWo = Ho * Wo;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < P; i += (long long)gridDim.x * 256) {
+    const int n = (int)(i / HWo);
+    const int rem = (int)(i - (long long)n * HWo);
+    const int oy = rem / Wo, ox = rem - oy * Wo;
+    const Tap ty = source_taps(oy, sy, Hi), tx = source_taps(ox, sx, Wi);
+    const float* b = low + (size_t)n * Hi * Wi * ld;
+    const float* p00 = b + ((size_t)ty.i0 * Wi + tx.i0) * ld;
+    const float* p01 = b + ((size_t)ty.i0 * Wi + tx.i1) * ld;
+    const float* p10 = b + ((size_t)ty.i1 * Wi + tx.i0) * ld;
+    const float* p11 = b + ((size_t)ty.i1 * Wi + tx.i1) * ld;
+    const int t = ce_label_of(target[i]);
+    float m = -INFINITY, s = 0.f, vt = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+      float a[4], bb[4], c[4], d[4];
+      load4<float>(p00 + k0, a);
+      load4<float>(p01 + k0, bb);
+      load4<float>(p10 + k0, c);
+      load4<float>(p11 + k0, d);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (k0 + j < K) {
+          const float v = lerp4(ty, tx, a[j], bb[j], c[j], d[j]);
+          if (k0 + j == t) vt = v;
+          if (v > m) {
+            s = s * __expf(m - v) + 1.f;
+            m = v;
+          } else {
+            s += __expf(v - m);
+          }
+        }
+      }
+    }
+    const float lse = m + __logf(s);
+    lse_out[i] = lse;
+    if (t != ignore_index && t >= 0 && t < K) {
+      const float w = weight ? weight[t] : 1.f;
+      loss += w * (lse - vt);
+      wsum += w;
+    }
+  }
+  __shared__ float ra[4], rb[4];
+  loss = wave_sum(loss);
+  wsum = wave_sum(wsum);
+  if ((threadIdx.x & 63) == 0) {
+    ra[threadIdx.x >> 6] = loss;
+    rb[threadIdx.x >> 6] = wsum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x + 0] = (ra[0] + ra[1]) + (ra[2] + ra[3]);
+    partials[2 * blockIdx.x + 1] = (rb[0] + rb[1]) + (rb[2] + rb[3]);
+  }
+}
+
+// block = (image row (n, oy), chunk of KC classes): the per-pixel quantities of the row (label, coefficient, lse,
+// x tap) go to LDS tables once, phase 1 fills rowbuf[kl][ox] with the loss gradient of the row (one item = one
+// pixel x four classes, so all threads stay busy whatever the width), phase 2 reduces it along x onto the source
+// columns -> ws[n][k][oy][ix]
+constexpr int UCE_THREADS = 512;
+
+__global__ __launch_bounds__(UCE_THREADS) void upsample_ce_bwd_rows_kernel(
+    const float* __restrict__ low, int ld, int K, int KC, int Hi, int Wi, const float* __restrict__ target,
+    const float* __restrict__ weight, const float* __restrict__ lse, int Ho, int Wo, float sy, float sx,
+    int ignore_index, const float* __restrict__ coef_dev, float* __restrict__ ws) {
+  extern __shared__ float rowbuf[];  // [KC][Wo], then five [Wo] tables
+  int* t_i0 = reinterpret_cast<int*>(rowbuf + (size_t)KC * Wo);
+  float* t_w1 = reinterpret_cast<float*>(t_i0 + Wo);
+  float* t_c = t_w1 + Wo;
+  float* t_e = t_c + Wo;
+  int* t_t = reinterpret_cast<int*>(t_e + Wo);
+  const int n = blockIdx.x / Ho, oy = blockIdx.x - n * Ho;
+  const int kbase = blockIdx.y * KC;
+  const int kend = min(K, kbase + KC);
+  const float coef = *coef_dev;
+  const Tap ty = source_taps(oy, sy, Hi);
+  const size_t row_i = ((size_t)n * Ho + oy) * Wo;
+  for (int ox = threadIdx.x; ox < Wo; ox += UCE_THREADS) {
+    const int t = ce_label_of(target[row_i + ox]);
+    const bool valid = t != ignore_index && t >= 0 && t < K;
+    const Tap tx = source_taps(ox, sx, Wi);
+    t_i0[ox] = tx.i0;
+    t_w1[ox] = tx.w1;
+    t_c[ox] = valid ? coef * (weight ? weight[t] : 1.f) : 0.f;
+    t_e[ox] = lse[row_i + ox];
+    t_t[ox] = valid ? t : -1;
+  }
+  __syncthreads();
+  const float* r0 = low + ((size_t)n * Hi + ty.i0) * Wi * ld;
+  const float* r1 = low + ((size_t)n * Hi + ty.i1) * Wi * ld;
+  const int nq = (kend - kbase + 3) >> 2;
+  for (int item = threadIdx.x; item < nq * Wo; item += UCE_THREADS) {
+    const int q = item / Wo, ox = item - q * Wo;
+    const int k0 = kbase + q * 4;
+    const int t = t_t[ox];
+    const int i0 = t_i0[ox], i1 = i0 + (i0 < Wi - 1 ? 1 : 0);
+    Tap tx;
+    tx.w1 = t_w1[ox];
+    tx.w0 = 1.f - tx.w1;
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t >= 0) {
+      const float c = t_c[ox], e = t_e[ox];
+      float a[4], bb[4], cc[4], d[4];
+      load4<float>(r0 + (size_t)i0 * ld + k0, a);
+      load4<float>(r0 + (size_t)i1 * ld + k0, bb);
+      load4<float>(r1 + (size_t)i0 * ld + k0, cc);
+      load4<float>(r1 + (size_t)i1 * ld + k0, d);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        g[j] = c * (__expf(lerp4(ty, tx, a[j], bb[j], cc[j], d[j]) - e) - (k0 + j == t ? 1.f : 0.f));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (k0 + j < kend) rowbuf[(size_t)(q * 4 + j) * Wo + ox] = g[j];
+  }
+  __syncthreads();
+  const int nk = kend - kbase;
+  for (int idx = threadIdx.x; idx < nk * Wi; idx += UCE_THREADS) {
+    const int kl = idx / Wi, ix = idx - kl * Wi;
+    int lo, hi;
+    reader_range(ix, sx, Wo, lo, hi);
+    const float* row = rowbuf + (size_t)kl * Wo;
+    float a = 0.f;
+    for (int ox = lo; ox <= hi; ++ox) {
+      const int i0 = t_i0[ox];
+      const float l = t_w1[ox];
+      const float w = (i0 == ix ? 1.f - l : 0.f) + (i0 + (i0 < Wi - 1 ? 1 : 0) == ix ? l : 0.f);
+      if (w != 0.f) a = fmaf(w, row[ox], a);
+    }
+    ws[(((size_t)n * K + kbase + kl) * Ho + oy) * Wi + ix] = a;
+  }
+}
+
 static bool aligned_to(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 
 }  // namespace segk
@@ -443,5 +595,61 @@ extern "C" int segk_upsample_bwd(const void* dout, int dout_dtype, int dout_layo
     SEGK_REQUIRE(false, "upsample_bwd: bad layout %d", dout_layout);
   }
   SEGK_CHECK_LAUNCH("upsample_bwd");
+  return SEGK_OK;
+}
+
+extern "C" int segk_upsample_ce_fwd(const float* low, int low_ld, int N, int K, int Hi, int Wi, const float* target,
+                                    const float* weight, int Ho, int Wo, int ignore_index, float* lse, float* partials,
+                                    float* sums, segk_stream_t stream) {
+  SEGK_REQUIRE(low && target && lse && partials && sums, "upsample_ce_fwd: null pointer");
+  SEGK_REQUIRE(N > 0 && K > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "upsample_ce_fwd: bad shape");
+  SEGK_REQUIRE(low_ld % 4 == 0 && low_ld >= round_up(K, 4) && aligned_to(low, 16),
+               "upsample_ce_fwd: logits need a 16-byte aligned base and ld %% 4 == 0, ld >= K rounded up to 4 (ld=%d K=%d)",
+               low_ld, K);
+  SEGK_REQUIRE((long long)Ho * Wo < 2147483647LL, "upsample_ce_fwd: image too large");
+  const long long P = (long long)N * Ho * Wo;
+  const int rows = ce_partial_rows(P);
+  hipStream_t st = (hipStream_t)stream;
+  upsample_ce_fwd_kernel<<<rows, 256, 0, st>>>(low, low_ld, K, Hi, Wi, target, weight, Ho, Wo, P, host_scale(Hi, Ho),
+                                               host_scale(Wi, Wo), ignore_index, lse, partials);
+  SEGK_CHECK_LAUNCH("upsample_ce_fwd");
+  return launch_ce_finish(partials, rows, sums, st);
+}
+
+extern "C" int segk_upsample_ce_bwd(const float* low, int low_ld, int N, int K, int Hi, int Wi, const float* target,
+                                    const float* weight, const float* lse, int Ho, int Wo, int ignore_index,
+                                    const float* coef_dev, float* workspace, float* dlow, int dlow_ld, int dlow_cpad,
+                                    segk_stream_t stream) {
+  SEGK_REQUIRE(low && target && lse && coef_dev && workspace && dlow, "upsample_ce_bwd: null pointer");
+  SEGK_REQUIRE(N > 0 && K > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && dlow_cpad >= K && dlow_ld >= dlow_cpad,
+               "upsample_ce_bwd: bad shape K=%d cpad=%d ld=%d", K, dlow_cpad, dlow_ld);
+  SEGK_REQUIRE(low_ld % 4 == 0 && low_ld >= round_up(K, 4) && aligned_to(low, 16),
+               "upsample_ce_bwd: logits need a 16-byte aligned base and ld %% 4 == 0, ld >= K rounded up to 4 (ld=%d K=%d)",
+               low_ld, K);
+  int KC = K < 32 ? round_up(K, 4) : 32;   // classes per workgroup: KC + 5 rows of Wo floats must fit in LDS
+  while (KC > 4 && (long long)(KC + 5) * Wo * 4 > 131072) KC = (KC / 2 + 3) & ~3;
+  SEGK_UNSUPPORTED((long long)(KC + 5) * Wo * 4 <= 131072, "upsample_ce_bwd: output width %d too large", Wo);
+  SEGK_REQUIRE((long long)N * Ho < 2147483647LL && (long long)N * Hi <= 65535 && ceil_div(dlow_cpad, UC_CH) <= 65535 &&
+                   ceil_div(K, KC) <= 65535,
+               "upsample_ce_bwd: grid too large");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)(KC + 5) * Wo * sizeof(float);
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute((const void*)upsample_ce_bwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) !=
+        hipSuccess) {
+      set_error("upsample_ce_bwd: cannot raise the dynamic LDS limit");
+      return SEGK_HIP_ERROR;
+    }
+    configured = true;
+  }
+  const float sy = host_scale(Hi, Ho), sx = host_scale(Wi, Wo);
+  upsample_ce_bwd_rows_kernel<<<dim3(N * Ho, ceil_div(K, KC)), UCE_THREADS, lds, st>>>(low, low_ld, K, KC, Hi, Wi, target, weight, lse,
+                                                                            Ho, Wo, sy, sx, ignore_index, coef_dev,
+                                                                            workspace);
+  SEGK_CHECK_LAUNCH("upsample_ce_bwd rows");
+  dim3 grid(ceil_div(Wi, UC_PIX), N * Hi, ceil_div(dlow_cpad, UC_CH));
+  upsample_bwd_cols_kernel<float><<<grid, 256, 0, st>>>(workspace, K, Ho, Hi, Wi, sy, dlow, dlow_ld, dlow_cpad);
+  SEGK_CHECK_LAUNCH("upsample_ce_bwd cols");
   return SEGK_OK;
 }

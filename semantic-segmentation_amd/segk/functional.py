@@ -492,6 +492,47 @@ def cross_entropy(logit, target, weight=None, ignore_index=255, size_average=Tru
     return CrossEntropyFunction.apply(logit, target, weight, ignore_index, size_average, batch_average)
 
 
+class UpsampleCrossEntropyFunction(torch.autograd.Function):
+    """cross_entropy(interpolate_bilinear_ac(x, target.shape[1:]), target, ...) in two kernels each way, without
+    the full-resolution logits (/root/reference/modeling/deeplab.py:252 followed by utils/loss.py:23-35)."""
+
+    @staticmethod
+    def forward(ctx, x, target, weight, ignore_index, size_average, batch_average):
+        N, K, Hi, Wi = x.shape
+        Ho, Wo = int(target.shape[-2]), int(target.shape[-1])
+        v = pm_view_of(x)
+        if v is None or v.dtype != torch.float32 or v.stride(0) % 4 != 0 or v.stride(0) < ops.round_up(K, 4) \
+                or v.data_ptr() % 16 != 0:
+            buf = torch.zeros((N * Hi * Wi, ops.round_up(K, 4)), dtype=torch.float32, device=x.device)
+            buf[:, :K].copy_(v if v is not None else to_pm(x, torch.float32))
+            v = buf[:, :K]
+        tg = target if (target.dtype == torch.float32 and target.is_contiguous()) else target.float().contiguous()
+        sums, lse = ops.upsample_ce_fwd(v, N, Hi, Wi, tg, weight, Ho, Wo, ignore_index)
+        pack = torch.cat([sums, torch.full((1,), float(N), dtype=torch.float32, device=x.device)])
+        parallel.all_reduce_sum_(pack)  # global {sum w*nll, sum w, batch}
+        denom = torch.ones((), dtype=torch.float32, device=x.device)
+        if size_average:
+            denom = denom * pack[1]
+        if batch_average:
+            denom = denom * pack[2]
+        ctx.saved = (x, v, tg, weight, lse, denom, ignore_index, (N, K, Hi, Wi, Ho, Wo))
+        return pack[0] / denom
+
+    @staticmethod
+    def backward(ctx, g):
+        x, v, tg, weight, lse, denom, ignore_index, (N, K, Hi, Wi, Ho, Wo) = ctx.saved
+        coef = (g.float() / denom).reshape(1).contiguous()
+        dlow = ops.upsample_ce_bwd(v, N, Hi, Wi, tg, weight, lse, Ho, Wo, ignore_index, coef, ops.round_up(K, 32))
+        if pm_view_of(x) is not None and x.dtype == torch.float32:
+            return nchw_view_of(dlow[:, :K], N, Hi, Wi), None, None, None, None, None
+        return ops.pm_to_nchw(dlow[:, :K], N, Hi, Wi).to(x.dtype), None, None, None, None, None
+
+
+def upsample_cross_entropy(x, target, weight=None, ignore_index=255, size_average=True, batch_average=True):
+    """Loss of the bilinearly (align_corners) upsampled logits x against a target of the full size."""
+    return UpsampleCrossEntropyFunction.apply(x, target, weight, ignore_index, size_average, batch_average)
+
+
 # ----------------------------------------------------------------- SyncBN ----
 class SyncBNFunction(torch.autograd.Function):
     """Stand-alone batch norm on NCHW (or channels_last) tensors: the feeder's layers.  Optionally with the ReLU

@@ -28,6 +28,17 @@ class DeepLab(nn.Module):
         x = self.decoder(x, low_level_feat)
         return SF.interpolate_bilinear_ac(x, input.size()[2:])
 
+    def forward_loss(self, input, target, weight=None, ignore_index=255, size_average=True, batch_average=True):
+        """criterion(self(input), target) for the cross-entropy criterion of SegmentationLosses
+        (/root/reference/utils/loss.py:23-35), with the final upsample fused into the loss: the
+        [N, K, H, W] logits are never materialised.  Opt-in; `forward` still returns full-size logits."""
+        x, low_level_feat = self.backbone(input)
+        x = self.aspp(x)
+        x = self.decoder(x, low_level_feat)
+        if tuple(target.shape[-2:]) != tuple(input.shape[-2:]):
+            raise ValueError("target %s does not match the input size %s" % (tuple(target.shape), tuple(input.shape)))
+        return SF.upsample_cross_entropy(x, target, weight, ignore_index, size_average, batch_average)
+
     def _group(self, roots):
         for root in roots:
             for _, m in root.named_modules():

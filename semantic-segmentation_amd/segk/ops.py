@@ -642,6 +642,43 @@ def ce_bwd(logits, target, weight, lse, ignore_index, coef):
     return dl
 
 
+def _check_low(low, N, K, Hi, Wi, target, Ho, Wo, weight):
+    if low.dtype != torch.float32 or low.dim() != 2 or low.shape[0] != N * Hi * Wi or low.shape[1] != K:
+        raise ValueError("low-resolution logits must be a float32 pixel-major view [N*Hi*Wi, K]")
+    if target.dtype != torch.float32 or not target.is_contiguous() or target.numel() != N * Ho * Wo:
+        raise ValueError("target must be contiguous float32 [N,Ho,Wo]")
+    if weight is not None and (weight.dtype != torch.float32 or weight.numel() != K):
+        raise ValueError("class weight must be float32 [K]")
+
+
+def upsample_ce_fwd(low, N, Hi, Wi, target, weight, Ho, Wo, ignore_index):
+    """Loss sums of cross_entropy(interpolate(low, (Ho,Wo), align_corners=True), target) without the
+    full-resolution logits.  low: float32 pixel-major view [N*Hi*Wi, K].  -> (sums [2], lse [N,Ho,Wo])."""
+    _dev(low, target, weight)
+    K = low.shape[1]
+    _check_low(low, N, K, Hi, Wi, target, Ho, Wo, weight)
+    rows = call("segk_ce_partial_rows", N * Ho * Wo)
+    partials = torch.empty((rows, 2), dtype=torch.float32, device=low.device)
+    lse = torch.empty((N, Ho, Wo), dtype=torch.float32, device=low.device)
+    sums = torch.empty((2,), dtype=torch.float32, device=low.device)
+    call("segk_upsample_ce_fwd", _ptr(low), _pm(low)[0], N, K, Hi, Wi, _ptr(target), _ptr(weight), Ho, Wo,
+         ignore_index, _ptr(lse), _ptr(partials), _ptr(sums), _stream())
+    return sums, lse
+
+
+def upsample_ce_bwd(low, N, Hi, Wi, target, weight, lse, Ho, Wo, ignore_index, coef, cpad):
+    """-> float32 [N*Hi*Wi, cpad]: gradient of the fused loss with respect to low (channels K..cpad zero)."""
+    _dev(low, target, weight, lse, coef)
+    K = low.shape[1]
+    _check_low(low, N, K, Hi, Wi, target, Ho, Wo, weight)
+    n_ws = call("segk_upsample_bwd_workspace", NCHW, N, K, Ho, Wi)
+    ws = torch.empty((n_ws,), dtype=torch.float32, device=low.device)
+    dlow = torch.empty((N * Hi * Wi, cpad), dtype=torch.float32, device=low.device)
+    call("segk_upsample_ce_bwd", _ptr(low), _pm(low)[0], N, K, Hi, Wi, _ptr(target), _ptr(weight), _ptr(lse), Ho, Wo,
+         ignore_index, _ptr(coef), _ptr(ws), _ptr(dlow), cpad, cpad, _stream())
+    return dlow
+
+
 def argmax(logits):
     _dev(logits)
     if logits.dtype != torch.float32 or not logits.is_contiguous() or logits.dim() != 4:

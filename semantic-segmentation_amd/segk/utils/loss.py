@@ -39,6 +39,12 @@ class SegmentationLosses(object):
     def CrossEntropyLoss(self, logit, target):
         return self._ce(logit, target, self.batch_average)
 
+    def CrossEntropyLossUpsampled(self, logit_low, target):
+        """CrossEntropyLoss(F.interpolate(logit_low, target size, bilinear, align_corners=True), target) without the
+        full-size logits (the opt-in fused form; see DeepLab.forward_loss)."""
+        return SF.upsample_cross_entropy(logit_low, target, self._weight_on(logit_low.device), self.ignore_index,
+                                         self.size_average, self.batch_average)
+
     def FocalLoss(self, logit, target, gamma=2, alpha=0.5):
         # utils/loss.py:37-53: a scalar transform of the mean cross-entropy
         n = logit.size(0)
