@@ -301,6 +301,12 @@ int segk_upsample_ce_bwd(const float* low, int low_ld, int N, int K, int Hi, int
                          const float* coef_dev, float* workspace, float* dlow, int dlow_ld, int dlow_cpad,
                          segk_stream_t stream);
 
+/* np.argmax(F.interpolate(low, (Ho,Wo), bilinear, align_corners=True), axis=1) (train.py:215-217) without the
+ * full-resolution logits; same blend arithmetic as segk_upsample_fwd's NCHW output, so the predictions equal
+ * segk_argmax of that output bit for bit.  pred: int64 [N][Ho][Wo]. */
+int segk_upsample_argmax(const float* low, int low_ld, int N, int K, int Hi, int Wi, int Ho, int Wo, int64_t* pred,
+                         segk_stream_t stream);
+
 /* ---- evaluator ------------------------------------------------------------------------------ */
 /* np.argmax(logits, axis=1) (train.py:217): first maximal index, NaN counts as maximal. */
 int segk_argmax(const float* logits, int N, int K, int HW, int64_t* pred, segk_stream_t stream);

@@ -183,6 +183,14 @@ __global__ __launch_bounds__(256) void upsample_fwd_pm_kernel(const TI* __restri
 }
 
 // pixel-major -> NCHW fp32; thread = output pixel (x fastest => coalesced plane writes)
+// The bilinear blend with every product and sum rounded on its own (no fused multiply-add), so that the kernels
+// that materialise the upsampled logits and those that consume them on the fly see bit-identical values.
+__device__ __forceinline__ float lerp4(const Tap& ty, const Tap& tx, float a, float b, float c, float d) {
+  const float top = __fadd_rn(__fmul_rn(tx.w0, a), __fmul_rn(tx.w1, b));
+  const float bot = __fadd_rn(__fmul_rn(tx.w0, c), __fmul_rn(tx.w1, d));
+  return __fadd_rn(__fmul_rn(ty.w0, top), __fmul_rn(ty.w1, bot));
+}
+
 template <typename TI>
 __global__ __launch_bounds__(256) void upsample_fwd_nchw_kernel(const TI* __restrict__ in, int in_ld, int C, int Hi,
                                                                  int Wi, float* __restrict__ out, int Ho, int Wo,
@@ -208,8 +216,7 @@ __global__ __launch_bounds__(256) void upsample_fwd_nchw_kernel(const TI* __rest
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (c0 + j < C)
-        o[(size_t)(c0 + j) * plane] =
-            ty.w0 * (tx.w0 * v00[j] + tx.w1 * v01[j]) + ty.w1 * (tx.w0 * v10[j] + tx.w1 * v11[j]);
+        o[(size_t)(c0 + j) * plane] = lerp4(ty, tx, v00[j], v01[j], v10[j], v11[j]);
   }
 }
 
@@ -346,9 +353,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_cols_kernel(const float* __r
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int ce_label_of(float t) { return (int)(long long)t; }  // .long(): truncation
 
-__device__ __forceinline__ float lerp4(const Tap& ty, const Tap& tx, float a, float b, float c, float d) {
-  return ty.w0 * (tx.w0 * a + tx.w1 * b) + ty.w1 * (tx.w0 * c + tx.w1 * d);
-}
+
 
 __global__ __launch_bounds__(256) void upsample_ce_fwd_kernel(const float* __restrict__ low, int ld, int K, int Hi, int Wi,
                                                               const float* __restrict__ target,
@@ -408,6 +413,45 @@ __global__ __launch_bounds__(256) void upsample_ce_fwd_kernel(const float* __res
   if (threadIdx.x == 0) {
     partials[2 * blockIdx.x + 0] = (ra[0] + ra[1]) + (ra[2] + ra[3]);
     partials[2 * blockIdx.x + 1] = (rb[0] + rb[1]) + (rb[2] + rb[3]);
+  }
+}
+
+// np.argmax over the classes of the upsampled logits (train.py:215-217 after deeplab.py:252) without writing them:
+// first maximal index, a NaN is maximal.
+__global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* __restrict__ low, int ld, int K, int Hi, int Wi,
+                                                              int Ho, int Wo, long long P, float sy, float sx,
+                                                              int64_t* __restrict__ pred) {
+  const int HWo = Ho * Wo;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < P; i += (long long)gridDim.x * 256) {
+    const int n = (int)(i / HWo);
+    const int rem = (int)(i - (long long)n * HWo);
+    const int oy = rem / Wo, ox = rem - oy * Wo;
+    const Tap ty = source_taps(oy, sy, Hi), tx = source_taps(ox, sx, Wi);
+    const float* b = low + (size_t)n * Hi * Wi * ld;
+    const float* p00 = b + ((size_t)ty.i0 * Wi + tx.i0) * ld;
+    const float* p01 = b + ((size_t)ty.i0 * Wi + tx.i1) * ld;
+    const float* p10 = b + ((size_t)ty.i1 * Wi + tx.i0) * ld;
+    const float* p11 = b + ((size_t)ty.i1 * Wi + tx.i1) * ld;
+    float best = 0.f;
+    int bi = -1;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+      float a[4], bb[4], c[4], d[4];
+      load4<float>(p00 + k0, a);
+      load4<float>(p01 + k0, bb);
+      load4<float>(p10 + k0, c);
+      load4<float>(p11 + k0, d);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (k0 + j < K) {
+          const float v = lerp4(ty, tx, a[j], bb[j], c[j], d[j]);
+          if (bi < 0 || v > best || (v != v && best == best)) {
+            best = v;
+            bi = k0 + j;
+          }
+        }
+      }
+    }
+    pred[i] = bi;
   }
 }
 
@@ -651,5 +695,22 @@ extern "C" int segk_upsample_ce_bwd(const float* low, int low_ld, int N, int K, 
   dim3 grid(ceil_div(Wi, UC_PIX), N * Hi, ceil_div(dlow_cpad, UC_CH));
   upsample_bwd_cols_kernel<float><<<grid, 256, 0, st>>>(workspace, K, Ho, Hi, Wi, sy, dlow, dlow_ld, dlow_cpad);
   SEGK_CHECK_LAUNCH("upsample_ce_bwd cols");
+  return SEGK_OK;
+}
+
+extern "C" int segk_upsample_argmax(const float* low, int low_ld, int N, int K, int Hi, int Wi, int Ho, int Wo,
+                                    int64_t* pred, segk_stream_t stream) {
+  SEGK_REQUIRE(low && pred, "upsample_argmax: null pointer");
+  SEGK_REQUIRE(N > 0 && K > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "upsample_argmax: bad shape");
+  SEGK_REQUIRE(low_ld % 4 == 0 && low_ld >= round_up(K, 4) && aligned_to(low, 16),
+               "upsample_argmax: logits need a 16-byte aligned base and ld %% 4 == 0, ld >= K rounded up to 4 (ld=%d K=%d)",
+               low_ld, K);
+  SEGK_REQUIRE((long long)Ho * Wo < 2147483647LL, "upsample_argmax: image too large");
+  const long long P = (long long)N * Ho * Wo;
+  long long blocks = (P + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  upsample_argmax_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(low, low_ld, K, Hi, Wi, Ho, Wo, P, host_scale(Hi, Ho),
+                                                                      host_scale(Wi, Wo), pred);
+  SEGK_CHECK_LAUNCH("upsample_argmax");
   return SEGK_OK;
 }

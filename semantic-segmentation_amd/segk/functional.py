@@ -500,12 +500,7 @@ class UpsampleCrossEntropyFunction(torch.autograd.Function):
     def forward(ctx, x, target, weight, ignore_index, size_average, batch_average):
         N, K, Hi, Wi = x.shape
         Ho, Wo = int(target.shape[-2]), int(target.shape[-1])
-        v = pm_view_of(x)
-        if v is None or v.dtype != torch.float32 or v.stride(0) % 4 != 0 or v.stride(0) < ops.round_up(K, 4) \
-                or v.data_ptr() % 16 != 0:
-            buf = torch.zeros((N * Hi * Wi, ops.round_up(K, 4)), dtype=torch.float32, device=x.device)
-            buf[:, :K].copy_(v if v is not None else to_pm(x, torch.float32))
-            v = buf[:, :K]
+        v = _low_logits_pm(x)
         tg = target if (target.dtype == torch.float32 and target.is_contiguous()) else target.float().contiguous()
         sums, lse = ops.upsample_ce_fwd(v, N, Hi, Wi, tg, weight, Ho, Wo, ignore_index)
         pack = torch.cat([sums, torch.full((1,), float(N), dtype=torch.float32, device=x.device)])
@@ -526,6 +521,24 @@ class UpsampleCrossEntropyFunction(torch.autograd.Function):
         if pm_view_of(x) is not None and x.dtype == torch.float32:
             return nchw_view_of(dlow[:, :K], N, Hi, Wi), None, None, None, None, None
         return ops.pm_to_nchw(dlow[:, :K], N, Hi, Wi).to(x.dtype), None, None, None, None, None
+
+
+def _low_logits_pm(x):
+    """float32 pixel-major view [N*Hi*Wi, K] of low-resolution logits the fused kernels can read (copy if needed)."""
+    N, K, Hi, Wi = x.shape
+    v = pm_view_of(x)
+    if v is None or v.dtype != torch.float32 or v.stride(0) % 4 != 0 or v.stride(0) < ops.round_up(K, 4) \
+            or v.data_ptr() % 16 != 0:
+        buf = torch.zeros((N * Hi * Wi, ops.round_up(K, 4)), dtype=torch.float32, device=x.device)
+        buf[:, :K].copy_(v if v is not None else to_pm(x, torch.float32))
+        v = buf[:, :K]
+    return v
+
+
+def upsample_argmax(x, size):
+    """np.argmax(interpolate_bilinear_ac(x, size), axis=1) on the device without the full-size logits."""
+    N, K, Hi, Wi = x.shape
+    return ops.upsample_argmax(_low_logits_pm(x), N, Hi, Wi, int(size[0]), int(size[1]))
 
 
 def upsample_cross_entropy(x, target, weight=None, ignore_index=255, size_average=True, batch_average=True):

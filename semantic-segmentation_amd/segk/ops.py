@@ -679,6 +679,17 @@ def upsample_ce_bwd(low, N, Hi, Wi, target, weight, lse, Ho, Wo, ignore_index, c
     return dlow
 
 
+def upsample_argmax(low, N, Hi, Wi, Ho, Wo):
+    """argmax over the classes of the bilinearly (align_corners) upsampled logits; low: float32 pixel-major view
+    [N*Hi*Wi, K].  -> int64 [N,Ho,Wo]."""
+    _dev(low)
+    if low.dtype != torch.float32 or low.dim() != 2 or low.shape[0] != N * Hi * Wi:
+        raise ValueError("low-resolution logits must be a float32 pixel-major view [N*Hi*Wi, K]")
+    pred = torch.empty((N, Ho, Wo), dtype=torch.int64, device=low.device)
+    call("segk_upsample_argmax", _ptr(low), _pm(low)[0], N, low.shape[1], Hi, Wi, Ho, Wo, _ptr(pred), _stream())
+    return pred
+
+
 def argmax(logits):
     _dev(logits)
     if logits.dtype != torch.float32 or not logits.is_contiguous() or logits.dim() != 4:

@@ -100,6 +100,16 @@ class Evaluator(object):
         self.add_batch(gt_image, pred)
         return pred
 
+    def add_low_logits(self, gt_image, low_logits):
+        """add_logits(gt, F.interpolate(low_logits, gt size, bilinear, align_corners=True)) without the full-size
+        logits (validation twin of DeepLab.forward_loss): upsample + argmax in one kernel, then the histogram."""
+        if not (isinstance(low_logits, torch.Tensor) and low_logits.is_cuda):
+            raise RuntimeError("add_low_logits expects the decoder output on the GPU")
+        from .. import functional as SF
+        pred = SF.upsample_argmax(low_logits.detach(), tuple(gt_image.shape[-2:]))
+        self.add_batch(gt_image, pred)
+        return pred
+
     def reset(self):
         self._host = np.zeros((self.num_class,) * 2)
         if self._cm is not None:

@@ -81,7 +81,7 @@ def test_forward_loss_equals_criterion_of_forward():
         torch.manual_seed(11)   # same dropout masks
         loss = model.forward_loss(image, target) if fused else crit(model(image), target)
         loss.backward()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
         grads.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
     # The feeder's MIOpen convolutions are not reproducible run to run (two unfused evaluations differ by 1.5e-4 in
     # the decoder output and by 2e-2 in the ASPP weight gradients at this tiny size), so this test only shows that
@@ -93,3 +93,26 @@ def test_forward_loss_equals_criterion_of_forward():
             continue
         a, b = grads[0][n].double(), grads[1][n].double()
         assert float((a - b).norm()) <= 1e-1 * float(a.norm()) + 1e-9, n
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_upsample_argmax_equals_argmax_of_upsample(case):
+    """Bit-exact: the fused kernel blends with the same rounded operations as the kernel that writes the logits."""
+    from segk import functional as SF, ops
+    from segk.utils.metrics import Evaluator
+    N, K, hi, wi, ho, wo = case
+    x, t, _ = _case(*case, seed=7)
+    x[0, :, 0, 0] = 0.5          # exact ties: the first class must win
+    if K > 2:
+        x[-1, 2, -1, -1] = float("nan")
+    xd = x.to(DEV)
+    full = SF.interpolate_bilinear_ac(xd, (ho, wo))
+    ref = ops.argmax(full)
+    got = SF.upsample_argmax(xd, (ho, wo))
+    assert torch.equal(ref, got)
+    assert np.array_equal(got.cpu().numpy(), ops_ref.predict(full.cpu().numpy()))
+    e1, e2 = Evaluator(K), Evaluator(K)
+    e1.add_logits(t.to(DEV), full)
+    e2.add_low_logits(t.to(DEV), xd)
+    assert np.array_equal(e1.confusion_matrix, e2.confusion_matrix)
+    assert np.array_equal(e1.confusion_matrix, ops_ref.confusion_matrix(t.numpy(), ref.cpu().numpy(), K))
