@@ -135,3 +135,16 @@ def sgd_step(w, g, buf, lr, momentum=0.9, weight_decay=5e-4):
     d = g + np.float32(weight_decay) * w
     buf = np.float32(momentum) * buf + d
     return w - np.float32(lr) * buf, buf
+
+
+# ------------------------------------------------- class-balanced weights ----
+def class_weights(label_batches, num_classes):
+    """utils/calculate_weights.py:8-27 without the file output: bincount of the labels inside [0, num_classes)
+    (cast through uint8 as the reference does), weight = 1 / ln(1.02 + frequency / total)."""
+    z = np.zeros((num_classes,))
+    for y in label_batches:
+        y = np.asarray(y)
+        mask = (y >= 0) & (y < num_classes)
+        z += np.bincount(y[mask].astype(np.uint8), minlength=num_classes)
+    total = np.sum(z)
+    return np.array([1 / (np.log(1.02 + (f / total))) for f in z])

@@ -116,3 +116,18 @@ def test_upsample_argmax_equals_argmax_of_upsample(case):
     e2.add_low_logits(t.to(DEV), xd)
     assert np.array_equal(e1.confusion_matrix, e2.confusion_matrix)
     assert np.array_equal(e1.confusion_matrix, ops_ref.confusion_matrix(t.numpy(), ref.cpu().numpy(), K))
+
+
+def test_class_balanced_weights_match_oracle():
+    from segk.utils.calculate_weights import calculate_weigths_labels
+    g = torch.Generator().manual_seed(9)
+    K = 21
+    batches = []
+    for _ in range(3):
+        y = torch.randint(0, K, (2, 40, 33), generator=g).float()
+        y[torch.rand(y.shape, generator=g) < 0.2] = 255.0
+        y[0, 0, :5] = -1.0
+        batches.append({"label": y})
+    got = calculate_weigths_labels("synthetic", batches, K)
+    ref = ops_ref.class_weights([b["label"].numpy() for b in batches], K)
+    assert got.dtype == np.float64 and np.array_equal(got, ref)
