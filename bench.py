@@ -192,8 +192,11 @@ def main():
             out = model(image)
             loss = criterion(out, target)
         loss.backward()
-        buckets.reduce()
-        opt.step()
+        if world > 1 and args.optimizer == "hip":
+            opt.step(flat_grads=buckets.reduce_flat())   # the optimizer reads the all-reduced buckets in place
+        else:
+            buckets.reduce()
+            opt.step()
         return loss
 
     for i in range(args.warmup):

@@ -321,9 +321,10 @@ int segk_confmat(const void* gt, int gt_is_i64, const int64_t* pred, long long c
  * over many tensors in one launch.  The caller cuts each tensor into chunks (any size; 64 Ki elements is a good one)
  * and passes a device table with one entry per chunk:
  *   d = grad + weight_decay * master;  momentum_buf = momentum * momentum_buf + d;  master -= lr * momentum_buf
- * (a zero-initialised buffer reproduces torch's first step, which copies d).  dtype is the type of param and
- * grad: for SEGK_F32, master must be the parameter itself; for SEGK_BF16, master is its fp32 copy and param
- * receives the rounded result. */
+ * (a zero-initialised buffer reproduces torch's first step, which copies d).  dtype: low byte = type of param
+ * (for SEGK_F32, master must be the parameter itself; for SEGK_BF16, master is its fp32 copy and param receives
+ * the rounded result), second byte = type of grad (an fp32 parameter takes an fp32 gradient; a bf16 parameter
+ * takes its own bf16 gradient or an fp32 one, e.g. a slice of an all-reduced bucket). */
 typedef struct {
   void* param;
   const void* grad;
@@ -332,6 +333,16 @@ typedef struct {
   int n;
   int dtype;
 } segk_sgd_chunk;
+/* dst[i] = (float)src[i] for every chunk of a device table: packs the gradients of many parameters (fp32 or
+ * bf16) into flat fp32 buckets, the operand of the gradient all-reduce that replaces DataParallel's reduce-add
+ * (train.py:106-109). */
+typedef struct {
+  const void* src;
+  float* dst;
+  int n;
+  int dtype;
+} segk_gather_chunk;
+int segk_gather_f32(const segk_gather_chunk* table, int n_chunks, segk_stream_t stream);
 int segk_sgd_step(const segk_sgd_chunk* table, int n_chunks, float lr, float momentum, float weight_decay,
                   segk_stream_t stream);
 

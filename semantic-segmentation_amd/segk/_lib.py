@@ -108,6 +108,7 @@ SIGNATURES = {
     "segk_upsample_ce_bwd": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                              c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "segk_upsample_argmax": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "segk_gather_f32": [c_void_p, c_int, c_void_p],
     "segk_sgd_step": [c_void_p, c_int, c_float, c_float, c_float, c_void_p],
 }
 _RESTYPES = {"segk_last_error": ctypes.c_char_p, "segk_upsample_bwd_workspace": c_ll}

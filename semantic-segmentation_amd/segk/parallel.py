@@ -70,6 +70,10 @@ class GradientBuckets:
     fp32 buckets of about `bucket_mb`; `reduce()` copies grads in, all-reduces each bucket asynchronously
     and copies the sums back.  SUM, not mean: every rank's loss is already divided by the global
     normaliser, so summed gradients equal the single-device gradients of the whole batch.
+
+    `reduce_flat()` is the form for `segk.optim.SGD.step(flat_grads=buckets)`: one HIP launch per bucket packs
+    the gradients (fp32 or bf16, in storage order) into the bucket, the all-reduced sums stay there and the
+    optimizer reads them through `view_of(p)`; no per-parameter copy kernels in either direction.
     """
 
     def __init__(self, params, bucket_mb=32.0):
@@ -86,11 +90,76 @@ class GradientBuckets:
         if cur:
             self.buckets.append(cur)
         self._flat = None
+        self._gather = None
+
+    def view_of(self, p):
+        """The slice of a flat bucket that holds parameter p's (summed) gradient after reduce_flat()."""
+        self._buffers()
+        return self._views[id(p)]
+
+    def reduce_flat(self):
+        """Pack every gradient into its bucket (always, also on one rank) and all-reduce the buckets."""
+        import ctypes
+
+        import numpy as np
+
+        from . import _lib
+        from ._tables import StagedTable, base_ptrs, chunks_of
+        flats = self._buffers()
+        if self._gather is None:
+            entry = np.dtype([("src", "<u8"), ("dst", "<u8"), ("n", "<i4"), ("dtype", "<i4")])
+            self._gather = []
+            for flat, bucket in zip(flats, self.buckets):
+                tidx, offs, ns = chunks_of(bucket)
+                t = np.zeros(len(tidx), dtype=entry)
+                t["dst"] = base_ptrs([self._views[id(p)] for p in bucket], tidx) + offs * np.uint64(4)
+                t["n"] = ns
+                t["dtype"] = np.asarray([_lib.BF16 if p.dtype == torch.bfloat16 else _lib.F32 for p in bucket],
+                                        dtype=np.int32)[tidx]
+                esz = np.asarray([p.element_size() for p in bucket], dtype=np.uint64)[tidx]
+                self._gather.append((StagedTable(t, flat.device), tidx, offs * esz))
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        works = []
+        for flat, bucket, (staged, tidx, goff) in zip(flats, self.buckets, self._gather):
+            ptrs = np.zeros(len(bucket), dtype=np.uint64)
+            for k, p in enumerate(bucket):
+                g = p.grad
+                if g is None:
+                    continue
+                if g.dtype != p.dtype or g.stride() != p.stride():
+                    raise RuntimeError("GradientBuckets: gradient of a %s parameter with strides %s is %s with strides %s"
+                                       % (p.dtype, p.stride(), g.dtype, g.stride()))
+                ptrs[k] = g.data_ptr()
+            per_chunk = ptrs[tidx]
+            live = per_chunk != 0
+            if not live.all():
+                flat.zero_()   # a parameter without a gradient on this rank contributes zeros
+            staged.table["src"] = per_chunk + goff
+            n = staged.upload(None if live.all() else live)
+            if n:
+                _lib.call("segk_gather_f32", ctypes.c_void_p(staged.ptr()), n, stream)
+            if not is_distributed():
+                works.append(None)
+            elif _host_staged(flat):
+                all_reduce_sum_(flat)
+                works.append(None)
+            else:
+                works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+        for w in works:
+            if w is not None:
+                w.wait()
+        return self
 
     def _buffers(self):
         if self._flat is None:
             self._flat = [torch.zeros(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device)
                           for b in self.buckets]
+            self._views = {}
+            for flat, bucket in zip(self._flat, self.buckets):
+                off = 0
+                for p in bucket:
+                    self._views[id(p)] = flat[off:off + p.numel()]
+                    off += p.numel()
         return self._flat
 
     def reduce(self):

@@ -139,10 +139,15 @@ def run_gpu(rank, world, outdir):
     from segk import parallel
     per = GPU_N // world
     net, loss, out = gpu_case("cuda:0", (rank * per, (rank + 1) * per), True)
+    buckets = parallel.GradientBuckets(list(net.parameters()), bucket_mb=0.5)
+    # the flat form first (it leaves p.grad alone), then the copy-back form: both must hold the same sums
+    buckets.reduce_flat()
+    flat = {n: buckets.view_of(p).detach().reshape(p.shape).cpu().numpy() for n, p in net.named_parameters()}
     parallel.GradientBuckets(list(net.parameters()), bucket_mb=0.5).reduce()
     res = {"loss": np.array([float(loss.detach())]), "out": out.detach().cpu().numpy()}
     for n, p in net.named_parameters():
         res["d/" + n] = p.grad.detach().cpu().numpy()
+        res["f/" + n] = flat[n]
     for n, b in net.named_buffers():
         if b.is_floating_point():
             res["b/" + n] = b.detach().cpu().numpy()

@@ -89,3 +89,42 @@ def test_sgd_bf16_parameters_keep_fp32_master():
     o3 = SGD(lin.parameters(), lr=0.1, low_precision=[lin.weight])
     sd = o3.full_precision_state_dict(lin)
     assert sd["weight"].dtype == torch.float32 and lin.weight.dtype == torch.bfloat16
+
+
+@pytest.mark.gpu
+def test_sgd_reads_flat_gradient_buckets():
+    """reduce_flat() + step(flat_grads=...) on one rank equals the plain step (mixed fp32 / bf16 parameters, one
+    channels_last, one without a gradient)."""
+    from segk.optim import SGD
+    from segk.parallel import GradientBuckets
+    dev = "cuda"
+    init = _grads(SHAPES, 2, dev)
+
+    def make():
+        ps = [torch.nn.Parameter(t.clone()) for t in init]
+        ps[3].data = ps[3].data.contiguous(memory_format=torch.channels_last)
+        return ps, SGD(ps, lr=0.05, momentum=0.9, weight_decay=5e-4, low_precision=[ps[3], ps[5]])
+
+    a, oa = make()
+    b, ob = make()
+    buckets = GradientBuckets(b, bucket_mb=0.5)
+    assert len(buckets.buckets) > 1
+    for it in range(3):
+        gs = _grads(SHAPES, 30 + it, dev)
+        for ps in (a, b):
+            for k, (p, g) in enumerate(zip(ps, gs)):
+                if k == 1:
+                    p.grad = None
+                    continue
+                g = g.to(p.dtype)
+                p.grad = g.contiguous(memory_format=torch.channels_last) if k == 3 else g.clone()
+        oa.step()
+        ob.step(flat_grads=buckets.reduce_flat())
+    torch.cuda.synchronize()
+    for k, (p, q) in enumerate(zip(a, b)):
+        if k == 1:
+            # no gradient: the plain step skips the parameter, the flat step sees a zero gradient and decays it
+            assert torch.equal(p.detach(), init[1])
+            continue
+        assert torch.equal(p.detach(), q.detach()), k
+        assert torch.equal(oa.state[p]["master"], ob.state[q]["master"]), k

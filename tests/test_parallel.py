@@ -95,3 +95,6 @@ def test_two_ranks_equal_one_rank_hip_modules():
         if k.startswith("d/"):
             assert np.array_equal(ranks[0][k], ranks[1][k]), k
             assert rel_l2(ranks[0][k], v) < 2e-2, (k, rel_l2(ranks[0][k], v))
+            # the flat buckets the device optimizer reads hold the same sums as the copied-back gradients
+            f = "f/" + k[2:]
+            assert np.array_equal(ranks[0][f], ranks[0][k]) and np.array_equal(ranks[1][f], ranks[0][k]), f
