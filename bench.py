@@ -180,7 +180,8 @@ def main():
         opt = torch.optim.SGD(groups, momentum=0.9, weight_decay=5e-4, nesterov=False)
     criterion = SegmentationLosses(weight=None, cuda=True).build_loss("ce")
     scheduler = LR_Scheduler("poly", 0.007, 50, 1000, quiet=True)
-    buckets = parallel.GradientBuckets([p for g in opt.param_groups for p in g["params"]])
+    buckets = parallel.GradientBuckets([p for g in opt.param_groups for p in g["params"]],
+                                       overlap=world > 1 and args.optimizer == "hip")
     image, target = synthetic_batch(args.batch, args.size, args.classes, dev, 1 + rank)
 
     def step(i):

@@ -76,7 +76,10 @@ class GradientBuckets:
     optimizer reads them through `view_of(p)`; no per-parameter copy kernels in either direction.
     """
 
-    def __init__(self, params, bucket_mb=32.0):
+    def __init__(self, params, bucket_mb=32.0, overlap=False):
+        """overlap=True: a hook on every parameter starts a bucket's pack + all-reduce the moment its last gradient
+        has been accumulated, so the collectives run under the rest of backward; reduce_flat() then only starts
+        the buckets still missing (parameters without a gradient) and waits."""
         self.params = [p for p in params if p.requires_grad]
         limit = int(bucket_mb * 1024 * 1024 / 4)
         self.buckets = []
@@ -91,16 +94,29 @@ class GradientBuckets:
             self.buckets.append(cur)
         self._flat = None
         self._gather = None
+        self._works = {}
+        self._seen = set()
+        self._pending = [len(b) for b in self.buckets]
+        self._bucket_of = {id(p): k for k, b in enumerate(self.buckets) for p in b}
+        if overlap:
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def _on_grad(self, p):
+        if id(p) in self._seen:   # a second backward in the same step: the bucket is packed again at reduce_flat()
+            return
+        self._seen.add(id(p))
+        k = self._bucket_of[id(p)]
+        self._pending[k] -= 1
+        if self._pending[k] == 0:
+            self._start(k)
 
     def view_of(self, p):
         """The slice of a flat bucket that holds parameter p's (summed) gradient after reduce_flat()."""
         self._buffers()
         return self._views[id(p)]
 
-    def reduce_flat(self):
-        """Pack every gradient into its bucket (always, also on one rank) and all-reduce the buckets."""
-        import ctypes
-
+    def _tables(self):
         import numpy as np
 
         from . import _lib
@@ -118,36 +134,54 @@ class GradientBuckets:
                                         dtype=np.int32)[tidx]
                 esz = np.asarray([p.element_size() for p in bucket], dtype=np.uint64)[tidx]
                 self._gather.append((StagedTable(t, flat.device), tidx, offs * esz))
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        works = []
-        for flat, bucket, (staged, tidx, goff) in zip(flats, self.buckets, self._gather):
-            ptrs = np.zeros(len(bucket), dtype=np.uint64)
-            for k, p in enumerate(bucket):
-                g = p.grad
-                if g is None:
-                    continue
-                if g.dtype != p.dtype or g.stride() != p.stride():
-                    raise RuntimeError("GradientBuckets: gradient of a %s parameter with strides %s is %s with strides %s"
-                                       % (p.dtype, p.stride(), g.dtype, g.stride()))
-                ptrs[k] = g.data_ptr()
-            per_chunk = ptrs[tidx]
-            live = per_chunk != 0
-            if not live.all():
-                flat.zero_()   # a parameter without a gradient on this rank contributes zeros
-            staged.table["src"] = per_chunk + goff
-            n = staged.upload(None if live.all() else live)
-            if n:
-                _lib.call("segk_gather_f32", ctypes.c_void_p(staged.ptr()), n, stream)
-            if not is_distributed():
-                works.append(None)
-            elif _host_staged(flat):
-                all_reduce_sum_(flat)
-                works.append(None)
-            else:
-                works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
-        for w in works:
+        return flats
+
+    def _start(self, k):
+        """Pack bucket k from the gradients as they are now and start its all-reduce."""
+        import ctypes
+
+        import numpy as np
+
+        from . import _lib
+        flat, bucket = self._tables()[k], self.buckets[k]
+        staged, tidx, goff = self._gather[k]
+        ptrs = np.zeros(len(bucket), dtype=np.uint64)
+        for i, p in enumerate(bucket):
+            g = p.grad
+            if g is None:
+                continue
+            if g.dtype != p.dtype or g.stride() != p.stride():
+                raise RuntimeError("GradientBuckets: gradient of a %s parameter with strides %s is %s with strides %s"
+                                   % (p.dtype, p.stride(), g.dtype, g.stride()))
+            ptrs[i] = g.data_ptr()
+        per_chunk = ptrs[tidx]
+        live = per_chunk != 0
+        if not live.all():
+            flat.zero_()   # a parameter without a gradient on this rank contributes zeros
+        staged.table["src"] = per_chunk + goff
+        n = staged.upload(None if live.all() else live)
+        if n:
+            _lib.call("segk_gather_f32", ctypes.c_void_p(staged.ptr()), n,
+                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if not is_distributed():
+            self._works[k] = None
+        elif _host_staged(flat):
+            all_reduce_sum_(flat)
+            self._works[k] = None
+        else:
+            self._works[k] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    def reduce_flat(self):
+        """Pack every gradient into its bucket (always, also on one rank), all-reduce the buckets and wait."""
+        for k in range(len(self.buckets)):
+            if k not in self._works:
+                self._start(k)
+        for w in self._works.values():
             if w is not None:
                 w.wait()
+        self._works = {}
+        self._seen = set()
+        self._pending = [len(b) for b in self.buckets]
         return self
 
     def _buffers(self):

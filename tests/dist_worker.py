@@ -95,8 +95,9 @@ def run_cpu(rank, world, outdir):
 GPU_N, GPU_K = 4, 7
 
 
-def gpu_case(device, images, sync):
-    """Head + a small SyncBN'd stem standing in for the feeder, one SGD-free step; returns loss, grads."""
+def gpu_case(device, images, sync, overlap_buckets=None):
+    """Head + a small SyncBN'd stem standing in for the feeder, one SGD-free step; returns loss, grads.
+    overlap_buckets (MB): attach GradientBuckets(overlap=True) before backward and finish them (net.overlapped)."""
     from segk.modeling.aspp import build_aspp
     from segk.modeling.decoder import build_decoder
     from segk.modeling.sync_batchnorm import SynchronizedBatchNorm2d
@@ -129,9 +130,14 @@ def gpu_case(device, images, sync):
     tgt = torch.from_numpy(gen.labels(SEED, "gd/lab", (GPU_N, 41, 37), GPU_K, border=1, ignore_frac=0.2))
     tgt[0, :30] = 255
     tgt = tgt[lo:hi].to(device)
+    if overlap_buckets is not None:
+        from segk import parallel
+        net.overlapped = parallel.GradientBuckets(list(net.parameters()), bucket_mb=overlap_buckets, overlap=True)
     out = net(img)
     loss = SegmentationLosses(cuda=True).build_loss("ce")(out, tgt)
     loss.backward()
+    if overlap_buckets is not None:
+        net.overlapped.reduce_flat()
     return net, loss, out
 
 
@@ -139,6 +145,8 @@ def run_gpu(rank, world, outdir):
     from segk import parallel
     per = GPU_N // world
     net, loss, out = gpu_case("cuda:0", (rank * per, (rank + 1) * per), True)
+    # a second pass with hooks that start each bucket during backward: its sums must equal the ones started after
+    net2, loss2, _ = gpu_case("cuda:0", (rank * per, (rank + 1) * per), True, overlap_buckets=0.5)
     buckets = parallel.GradientBuckets(list(net.parameters()), bucket_mb=0.5)
     # the flat form first (it leaves p.grad alone), then the copy-back form: both must hold the same sums
     buckets.reduce_flat()
@@ -148,6 +156,8 @@ def run_gpu(rank, world, outdir):
     for n, p in net.named_parameters():
         res["d/" + n] = p.grad.detach().cpu().numpy()
         res["f/" + n] = flat[n]
+    for n, p in net2.named_parameters():
+        res["o/" + n] = net2.overlapped.view_of(p).detach().reshape(p.shape).cpu().numpy()
     for n, b in net.named_buffers():
         if b.is_floating_point():
             res["b/" + n] = b.detach().cpu().numpy()

@@ -98,3 +98,7 @@ def test_two_ranks_equal_one_rank_hip_modules():
             # the flat buckets the device optimizer reads hold the same sums as the copied-back gradients
             f = "f/" + k[2:]
             assert np.array_equal(ranks[0][f], ranks[0][k]) and np.array_equal(ranks[1][f], ranks[0][k]), f
+            # ... also when hooks start each bucket's all-reduce during backward (a second, identical pass)
+            o = "o/" + k[2:]
+            assert np.array_equal(ranks[0][o], ranks[1][o]), o
+            assert rel_l2(ranks[0][o], ranks[0][k]) < 1e-5, (o, rel_l2(ranks[0][o], ranks[0][k]))
