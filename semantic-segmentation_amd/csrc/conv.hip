@@ -52,6 +52,8 @@ struct ConvDev {
   const float* bias;
   const float* img_bias;
   double* stat;
+  long long m_begin;     // first pixel of this launch (a problem may be cut into a main and a tail launch)
+  long long stat_row0;   // statistic partial row of this launch's first pixel tile
 };
 
 template <typename T>
@@ -173,7 +175,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x4 (&acc)[G::
         double v = 0.0;
 #pragma unroll
         for (int w = 0; w < G::WPX; ++w) v += red[(w * 2 + which) * G::BCO + cl];
-        p.stat[bz * p.stat_batch + ((size_t)mt * 2 + which) * p.Cout + co] = v;
+        p.stat[bz * p.stat_batch + ((size_t)(p.stat_row0 + mt) * 2 + which) * p.Cout + co] = v;
       }
     }
   }
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(G::THREADS, (G::THREADS == 256 && G::BCO == 256) ? 
   const int nt = blockIdx.x % p.n_tiles;
   const long long mt = blockIdx.x / p.n_tiles;
   const int co0 = nt * G::BCO;
-  const long long m0 = mt * G::BPX;
+  const long long m0 = p.m_begin + mt * G::BPX;
   const long long bz = blockIdx.y;  // batch entry (batched GEMM use; 0 for convolutions)
 
   const int lc = tid % CH, lr = tid / CH;
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_pipe_kernel(const ConvDev p) 
   const int nt = blockIdx.x % p.n_tiles;
   const long long mt = blockIdx.x / p.n_tiles;
   const int co0 = nt * G::BCO;
-  const long long m0 = mt * G::BPX;
+  const long long m0 = p.m_begin + mt * G::BPX;
   const long long bz = blockIdx.y;
 
   // ---- loader geometry: this thread's rows of every half-tile ------------------------------
@@ -977,8 +979,9 @@ static int set_lds(K kernel, int bytes, const char* name) {
   return SEGK_OK;
 }
 
+// px_tiles < 0: every pixel tile from d.m_begin to the end
 template <typename T, int BKB, typename TO, typename G, int ABL = 0>
-static int launch_fwd(ConvDev& d, hipStream_t st, int batch = 1) {
+static int launch_fwd(ConvDev& d, hipStream_t st, int batch = 1, long long px_tiles = -1) {
   const int lds = 2 * (G::BCO + G::BPX) * BKB;
   static bool configured = false;  // per instantiation
   if (!configured) {
@@ -987,7 +990,8 @@ static int launch_fwd(ConvDev& d, hipStream_t st, int batch = 1) {
     configured = true;
   }
   d.n_tiles = ceil_div(d.Cout, G::BCO);
-  const long long blocks = ((d.M + G::BPX - 1) / G::BPX) * d.n_tiles;
+  if (px_tiles < 0) px_tiles = (d.M - d.m_begin + G::BPX - 1) / G::BPX;
+  const long long blocks = px_tiles * d.n_tiles;
   if (blocks >= 2147483647LL) {
     set_error("conv: too many tiles");
     return SEGK_INVALID_ARG;
@@ -1031,6 +1035,52 @@ static bool use_big_tile(const ConvDev& d, bool wide, int batch = 1) {
   if (force && (force[0] == 'b' || force[0] == 'h')) return true;
   const long long tiles = ((d.M + TileBig::BPX - 1) / TileBig::BPX) * (d.Cout / TileBig::BCO) * batch;
   return tiles >= 512;
+}
+
+// Tile plan of one forward launch.  With one 256 x 256 workgroup per CU a problem of T tiles takes ceil(T / CUs)
+// rounds; when the last round would be nearly empty (1041 tiles on 256 CUs: 17 tiles in round five) the big tile
+// only takes the whole rounds and the remaining pixels go to a second launch of 128 x 128 tiles, which fills the
+// chip four times finer.
+struct TilePlan {
+  bool big;
+  long long main_tiles;  // pixel tiles of the first launch
+  bool tail;             // remaining pixels in a second, small-tile launch
+};
+
+static int cu_count() {
+  static int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    return v;
+  }();
+  return n;
+}
+
+static TilePlan plan_tiles(const ConvDev& d, bool wide, int batch) {
+  TilePlan pl;
+  pl.big = use_big_tile(d, wide, batch);
+  pl.tail = false;
+  pl.main_tiles = (d.M + (pl.big ? TileBig::BPX : TileSmall::BPX) - 1) / (pl.big ? TileBig::BPX : TileSmall::BPX);
+  static const char* e = getenv("SEGK_CONV_TAIL");
+  if (pl.big && batch == 1 && !use_pipe() && !(e && e[0] == '0')) {
+    const long long n_co = d.Cout / TileBig::BCO, blocks = pl.main_tiles * n_co, slots = cu_count();
+    const long long rounds = blocks / slots, rem = blocks % slots;
+    if (rounds >= 1 && rem > 0 && rem * 10 <= slots * 3) {
+      const long long keep = rounds * slots / n_co;
+      if (keep >= 1 && keep < pl.main_tiles) {
+        pl.main_tiles = keep;
+        pl.tail = true;
+      }
+    }
+  }
+  return pl;
+}
+
+static int plan_stat_rows(const ConvDev& d, const TilePlan& pl) {
+  if (!pl.tail) return (int)pl.main_tiles;
+  return (int)(pl.main_tiles + (d.M - pl.main_tiles * TileBig::BPX + TileSmall::BPX - 1) / TileSmall::BPX);
 }
 
 }  // namespace segk
@@ -1085,6 +1135,7 @@ static bool fill_dev(const segk_conv_args* a, ConvDev& d) {
   d.out_batch_b = (long long)a->out_batch * dtype_size(a->out_dtype);
   d.dil_step = a->dil_step;
   d.stat_batch = 0;  // set once the tile geometry (= number of partial rows) is known
+  d.m_begin = 0; d.stat_row0 = 0;
   d.bias = a->bias; d.img_bias = a->img_bias; d.stat = a->stat_partials;
   return wide;
 }
@@ -1094,7 +1145,7 @@ extern "C" int segk_conv_stat_rows(const segk_conv_args* a) {
     return SEGK_INVALID_ARG;
   ConvDev d;
   const bool wide = fill_dev(a, d);
-  return ceil_div(d.M, use_big_tile(d, wide, a->batch > 1 ? a->batch : 1) ? TileBig::BPX : TileSmall::BPX);
+  return plan_stat_rows(d, plan_tiles(d, wide, a->batch > 1 ? a->batch : 1));
 }
 
 extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
@@ -1105,8 +1156,9 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
   const int batch = a->batch > 1 ? a->batch : 1;
   SEGK_REQUIRE(batch <= 65535 && (batch == 1 || (!a->bias && !a->img_bias)),
                "conv: batch=%d (biases are not batched)", batch);
-  const bool big = use_big_tile(d, wide, batch);
-  d.stat_batch = (long long)ceil_div(d.M, big ? TileBig::BPX : TileSmall::BPX) * 2 * d.Cout;
+  const TilePlan plan = plan_tiles(d, wide, batch);
+  const bool big = plan.big;
+  d.stat_batch = (long long)plan_stat_rows(d, plan) * 2 * d.Cout;
   hipStream_t st = (hipStream_t)stream;
   static const char* abl = getenv("SEGK_CONV_ABL");
   if (abl && abl[0] && big && use_pipe() && a->dtype == SEGK_BF16 && a->out_dtype == SEGK_BF16) {
@@ -1135,7 +1187,25 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
 #define SEGK_LAUNCH(T, TO)                                                          \
   (big ? launch_fwd<T, 128, TO, TileBig>(d, st, batch)                              \
        : (wide ? launch_fwd<T, 128, TO, TileSmall>(d, st, batch) : launch_fwd<T, 64, TO, TileSmall>(d, st, batch)))
-  if (a->dtype == SEGK_BF16 && big && use_pipe()) {
+  if (plan.tail) {
+    // whole rounds on the big tile, the remainder on the small one
+#define SEGK_SPLIT(T, TO)                                                               \
+  do {                                                                                  \
+    rc = launch_fwd<T, 128, TO, TileBig>(d, st, 1, plan.main_tiles);                    \
+    if (rc == SEGK_OK) {                                                                \
+      SEGK_CHECK_LAUNCH("conv_fwd");                                                    \
+      d.m_begin = plan.main_tiles * TileBig::BPX;                                       \
+      d.stat_row0 = plan.main_tiles;                                                    \
+      rc = launch_fwd<T, 128, TO, TileSmall>(d, st, 1);                                 \
+    }                                                                                   \
+  } while (0)
+    if (a->dtype == SEGK_BF16) {
+      if (a->out_dtype == SEGK_BF16) SEGK_SPLIT(bf16_t, bf16_t); else SEGK_SPLIT(bf16_t, float);
+    } else {
+      if (a->out_dtype == SEGK_BF16) SEGK_SPLIT(float, bf16_t); else SEGK_SPLIT(float, float);
+    }
+#undef SEGK_SPLIT
+  } else if (a->dtype == SEGK_BF16 && big && use_pipe()) {
     rc = a->out_dtype == SEGK_BF16 ? launch_pipe<bf16_t>(d, st, batch) : launch_pipe<float>(d, st, batch);
   } else if (a->dtype == SEGK_BF16) {
     rc = a->out_dtype == SEGK_BF16 ? SEGK_LAUNCH(bf16_t, bf16_t) : SEGK_LAUNCH(bf16_t, float);
@@ -1226,6 +1296,7 @@ extern "C" int segk_gemm_nt(const segk_gemm_args* a, segk_stream_t stream) {
   }
   d.out = (char*)a->C; d.out_ld = a->ldc; d.out_batch_b = a->c_batch * cs;
   d.dil_step = 0; d.stat_batch = 0;
+  d.m_begin = 0; d.stat_row0 = 0;
   d.bias = nullptr; d.img_bias = nullptr; d.stat = nullptr;
   const long long big_tiles = (long long)ceil_div(a->M, TileBig::BPX) * (a->N / TileBig::BCO) * a->batch;
   const bool big = wide && a->N % TileBig::BCO == 0 && big_tiles >= 512;
