@@ -15,6 +15,7 @@
 //   bf16 fragments are read with the transposing ds_read_b64_tr_b16 and fp32 fragments with ds_read_b32.
 //   The pixel range is split over workgroups; each split writes its own fp32 slab (summed later in fixed
 //   order, so results are reproducible: no float atomics).
+#include <math.h>
 #include <stdlib.h>
 
 #include <cstdio>
@@ -1026,6 +1027,17 @@ static bool use_pipe() {
   return e && e[0] == '1';
 }
 
+static int cu_count() {
+  static int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    return v;
+  }();
+  return n;
+}
+
 // Rows of statistic partials = pixel tiles of the geometry chosen for this problem.
 static bool use_big_tile(const ConvDev& d, bool wide, int batch = 1) {
   // the big tile needs 128-byte K rows, full 256-channel tiles and enough tiles to fill 256 CUs twice
@@ -1033,8 +1045,18 @@ static bool use_big_tile(const ConvDev& d, bool wide, int batch = 1) {
   static const char* force = getenv("SEGK_CONV_TILE");  // experiments: "small" / "big"
   if (force && force[0] == 's') return false;
   if (force && (force[0] == 'b' || force[0] == 'h')) return true;
+  // Rounds of workgroups each geometry needs (a last round under 15 % full is not counted: the CUs drift apart
+  // enough to absorb it, and the big tile hands such a remainder to a small-tile launch anyway).  One workgroup of
+  // the big tile per CU, two of the small one; a round of small tiles takes 0.63 of a round of big ones (measured
+  // on the ASPP convolutions), and covers a quarter of the output per workgroup.
   const long long tiles = ((d.M + TileBig::BPX - 1) / TileBig::BPX) * (d.Cout / TileBig::BCO) * batch;
-  return tiles >= 512;
+  const double cus = cu_count();
+  auto rounds = [](double r) {
+    const double whole = floor(r);
+    const double n = whole + (r - whole > 0.15 ? 1.0 : 0.0);
+    return n < 1.0 ? 1.0 : n;
+  };
+  return rounds(tiles / cus) < 0.63 * rounds(4.0 * tiles / (2.0 * cus));
 }
 
 // Tile plan of one forward launch.  With one 256 x 256 workgroup per CU a problem of T tiles takes ceil(T / CUs)
@@ -1046,17 +1068,6 @@ struct TilePlan {
   long long main_tiles;  // pixel tiles of the first launch
   bool tail;             // remaining pixels in a second, small-tile launch
 };
-
-static int cu_count() {
-  static int n = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-      v = 256;
-    return v;
-  }();
-  return n;
-}
 
 static TilePlan plan_tiles(const ConvDev& d, bool wide, int batch) {
   TilePlan pl;
