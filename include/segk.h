@@ -32,7 +32,8 @@ typedef enum {
   SEGK_INVALID_ARG = -1,
   SEGK_UNSUPPORTED_SHAPE = -2,
   SEGK_WORKSPACE_TOO_SMALL = -3,
-  SEGK_HIP_ERROR = -4
+  SEGK_HIP_ERROR = -4,
+  SEGK_RCCL_ERROR = -5
 } segk_status;
 
 typedef enum { SEGK_F32 = 0, SEGK_BF16 = 1 } segk_dtype;
@@ -345,6 +346,22 @@ typedef struct {
 int segk_gather_f32(const segk_gather_chunk* table, int n_chunks, segk_stream_t stream);
 int segk_sgd_step(const segk_sgd_chunk* table, int n_chunks, float lr, float momentum, float weight_decay,
                   segk_stream_t stream);
+
+/* ---- exchange step (one process per GPU) ------------------------------------------------------ */
+/* A process-wide RCCL communicator for hosts without a collective library of their own; it stands where the
+ * reference has SyncMaster / SlavePipe (modeling/sync_batchnorm/comm.py:18-129) and DataParallel's gradient
+ * reduce-add (train.py:106-109).  Rank 0 draws an id with segk_comm_unique_id and hands the 128 bytes to the other
+ * processes by any means; every rank then calls segk_comm_init with the GPU it will use made current.  The
+ * all-reduces are in-place SUMs, asynchronous on the given stream: [2C+1] fp64 batch-norm statistics, the three
+ * fp32 loss sums, fp32 gradient buckets, the int64 confusion matrix.  librccl is opened on first use.  The Python
+ * package reaches RCCL through torch.distributed instead (same library underneath). */
+typedef struct { char bytes[128]; } segk_comm_id;
+int segk_comm_unique_id(segk_comm_id* id);
+int segk_comm_init(const segk_comm_id* id, int rank, int world);
+int segk_comm_destroy(void);
+int segk_allreduce_f32(float* buf, long long count, segk_stream_t stream);
+int segk_allreduce_f64(double* buf, long long count, segk_stream_t stream);
+int segk_allreduce_i64(int64_t* buf, long long count, segk_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -109,6 +109,12 @@ SIGNATURES = {
                              c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "segk_upsample_argmax": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "segk_gather_f32": [c_void_p, c_int, c_void_p],
+    "segk_comm_unique_id": [c_void_p],
+    "segk_comm_init": [c_void_p, c_int, c_int],
+    "segk_comm_destroy": [],
+    "segk_allreduce_f32": [c_void_p, c_ll, c_void_p],
+    "segk_allreduce_f64": [c_void_p, c_ll, c_void_p],
+    "segk_allreduce_i64": [c_void_p, c_ll, c_void_p],
     "segk_sgd_step": [c_void_p, c_int, c_float, c_float, c_float, c_void_p],
 }
 _RESTYPES = {"segk_last_error": ctypes.c_char_p, "segk_upsample_bwd_workspace": c_ll}

@@ -128,3 +128,33 @@ def test_sgd_reads_flat_gradient_buckets():
             continue
         assert torch.equal(p.detach(), q.detach()), k
         assert torch.equal(oa.state[p]["master"], ob.state[q]["master"]), k
+
+
+@pytest.mark.gpu
+def test_c_abi_communicator_single_rank():
+    """segk_comm_*: RCCL opened on demand; on one rank an in-place SUM all-reduce leaves the buffers unchanged."""
+    import ctypes
+    from segk import _lib
+    lib = _lib.load()
+    torch.cuda.set_device(0)
+    cid = ctypes.create_string_buffer(128)
+    _lib.call("segk_comm_unique_id", cid)
+    _lib.call("segk_comm_init", cid, 0, 1)
+    try:
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        f = torch.arange(1025, dtype=torch.float32, device="cuda")
+        d = torch.arange(513, dtype=torch.float64, device="cuda") / 7
+        i = torch.arange(21 * 21 + 1, dtype=torch.int64, device="cuda") * (1 << 40)
+        f0, d0, i0 = f.clone(), d.clone(), i.clone()
+        _lib.call("segk_allreduce_f32", ctypes.c_void_p(f.data_ptr()), f.numel(), st)
+        _lib.call("segk_allreduce_f64", ctypes.c_void_p(d.data_ptr()), d.numel(), st)
+        _lib.call("segk_allreduce_i64", ctypes.c_void_p(i.data_ptr()), i.numel(), st)
+        torch.cuda.synchronize()
+        assert torch.equal(f, f0) and torch.equal(d, d0) and torch.equal(i, i0)
+        with pytest.raises(_lib.SegkError):
+            _lib.call("segk_comm_init", cid, 0, 1)      # one communicator per process
+    finally:
+        _lib.call("segk_comm_destroy")
+    with pytest.raises(_lib.SegkError):
+        _lib.call("segk_allreduce_f32", ctypes.c_void_p(f.data_ptr()), f.numel(), st)
+    assert lib is not None
