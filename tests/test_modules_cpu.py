@@ -57,3 +57,37 @@ def test_modules_refuse_host_tensors():
     for m in (_PAM_Module(64), _CAM_Module(64)):
         with pytest.raises((ValueError, SegkError, RuntimeError)):
             m(x)
+
+
+def test_chunk_tables_cover_every_element_once():
+    """Host logic of the multi-tensor launches (optimizer, gradient packing): chunking and storage-order views."""
+    import numpy as np
+    import torch
+    from segk import _tables
+    ts = [torch.zeros(n) for n in (1, 7, _tables.CHUNK, _tables.CHUNK + 1, 3 * _tables.CHUNK - 5)]
+    tidx, offs, ns = _tables.chunks_of(ts)
+    assert ns.max() <= _tables.CHUNK and ns.min() >= 1
+    for k, t in enumerate(ts):
+        sel = tidx == k
+        o, n = offs[sel].astype(np.int64), ns[sel].astype(np.int64)
+        assert o[0] == 0 and np.array_equal(o[1:], (o + n)[:-1]) and (o + n)[-1] == t.numel()
+    w = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).reshape(2, 3, 4, 5)
+    cl = w.contiguous(memory_format=torch.channels_last)
+    assert torch.equal(_tables.flat_storage(w), w.reshape(-1))
+    flat = _tables.flat_storage(cl)
+    assert flat.data_ptr() == cl.data_ptr() and torch.equal(flat, cl.permute(0, 2, 3, 1).reshape(-1))
+    import pytest
+    with pytest.raises(RuntimeError):
+        _tables.flat_storage(w[:, ::2])
+
+
+def test_gradient_buckets_partition_parameters_in_reverse_order():
+    import torch
+    from segk.parallel import GradientBuckets
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in (10, 300000, 5, 200000, 7)]
+    frozen = torch.nn.Parameter(torch.zeros(3), requires_grad=False)
+    b = GradientBuckets(ps + [frozen], bucket_mb=1.0)
+    order = [p for bucket in b.buckets for p in bucket]
+    assert [id(p) for p in order] == [id(p) for p in reversed(ps)]
+    assert all(sum(p.numel() for p in bucket) <= 262144 or len(bucket) == 1 for bucket in b.buckets)
+    assert all(id(p) != id(frozen) for p in order)
