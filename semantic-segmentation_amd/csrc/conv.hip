@@ -1001,6 +1001,186 @@ static int launch_fwd(ConvDev& d, hipStream_t st, int batch = 1, long long px_ti
   return SEGK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Forward / data gradient, small tile with LDS-DMA: 128 x 128 tile, bf16 operands, 128-byte K rows, one LDS stage
+// of 32 KB filled by global_load_lds (no staging registers), two barriers per tap step.  Nothing is overlapped
+// inside a workgroup on purpose: with ~100 VGPRs and 32 KB of LDS three to four workgroups share a CU, and while
+// one waits for its loads the others multiply.
+// ------------------------------------------------------------------------------------------------
+constexpr int DM_LDS = 2 * 128 * 128;
+
+template <typename TO>
+__global__ __launch_bounds__(256, 3) void conv_fwd_dma_kernel(const ConvDev p) {
+  typedef TileSmall G;
+  constexpr int BKB = 128, MI = G::MI, MJ = G::MJ;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [A 128 rows][B 128 rows] x 128 B, swizzled
+  __shared__ int taps_l[SEGK_MAX_SEG * 9];
+  __shared__ int ntaps_l[SEGK_MAX_SEG];
+  __shared__ unsigned int mask_l[2];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / G::WPX, wc = wave % G::WPX;
+  const int nt = blockIdx.x % p.n_tiles;
+  const long long mt = blockIdx.x / p.n_tiles;
+  const int co0 = nt * G::BCO;
+  const long long m0 = p.m_begin + mt * G::BPX;
+  const long long bz = blockIdx.y;
+
+  // loader geometry: piece q = i*4 + wave (i = 0..3) covers tile rows q*8 .. q*8+7; lane l -> row q*8 + (l>>3),
+  // LDS slot l&7, which holds source chunk (l&7) ^ (row&7)
+  const int lrow = lane >> 3;
+  const int lchunk = ((lane & 7) ^ lrow) << 4;
+  int wrow[4], ry[4], rx[4];
+  bool rvalid[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (i * 4 + wave) * 8 + lrow;
+    const int co = co0 + r;
+    wrow[i] = (co < p.Cout ? co : p.Cout - 1) - co0;
+    const long long m = m0 + r;
+    rvalid[i] = m < p.M;
+    const int rem = pixel_in_image(rvalid[i] ? m : 0, p.HW);
+    ry[i] = rem / p.W;
+    rx[i] = rem - ry[i] * p.W;
+  }
+
+  if (tid < 2) mask_l[tid] = 0u;
+  __syncthreads();
+  {
+    unsigned long long mine = 0ull;
+    for (int sg = 0; sg < p.nseg; ++sg) {
+      const int R = p.seg[sg].R, dil = p.seg[sg].dil + (int)blockIdx.y * p.dil_step;
+      for (int tap = 0; tap < R * R; ++tap) {
+        const int dy = (tap / R - (R >> 1)) * dil, dx = (tap % R - (R >> 1)) * dil;
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          any |= rvalid[i] && (unsigned)(ry[i] + dy) < (unsigned)p.H && (unsigned)(rx[i] + dx) < (unsigned)p.W;
+        if (any) mine |= 1ull << (sg * 9 + tap);
+      }
+    }
+    const unsigned int lo = (unsigned int)mine, hi = (unsigned int)(mine >> 32);
+    if (lo) atomicOr(&mask_l[0], lo);
+    if (hi) atomicOr(&mask_l[1], hi);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned long long all = ((unsigned long long)mask_l[1] << 32) | mask_l[0];
+    for (int sg = 0; sg < p.nseg; ++sg) {
+      int cnt = 0;
+      const int R = p.seg[sg].R;
+      for (int tap = 0; tap < R * R; ++tap)
+        if ((all >> (sg * 9 + tap)) & 1ull) taps_l[sg * 9 + cnt++] = tap;
+      ntaps_l[sg] = cnt;
+    }
+  }
+  __syncthreads();
+  int total = 0;
+  for (int sg = 0; sg < p.nseg; ++sg) total += ntaps_l[sg] * (p.seg[sg].ck_b / BKB);
+
+  f32x4 acc[MI][MJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (total > 0) {
+    int sg = 0;
+    while (ntaps_l[sg] == 0) ++sg;
+    int ti = 0, kc = 0, nkc = p.seg[sg].ck_b / BKB;
+    unsigned aoff[4], boff[4];
+    bool bok[4];
+    const char* abase = nullptr;
+    const char* bbase = nullptr;
+    auto setup_seg = [&]() {
+      const SegDev& s = p.seg[sg];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        aoff[i] = (unsigned)wrow[i] * (unsigned)s.w_ld_b + lchunk;
+        boff[i] = (unsigned)((i * 4 + wave) * 8 + lrow) * (unsigned)s.in_ld_b + lchunk;
+      }
+    };
+    auto setup_tap = [&]() {
+      const SegDev& s = p.seg[sg];
+      const int tap = taps_l[sg * 9 + ti];
+      const int R = s.R;
+      const int dil = s.dil + (int)bz * p.dil_step;
+      const int dy = (tap / R - (R >> 1)) * dil, dx = (tap % R - (R >> 1)) * dil;
+      abase = s.w + bz * s.w_batch_b + (long long)tap * s.w_tap_b + (long long)co0 * s.w_ld_b + (long long)kc * BKB;
+      bbase = s.in + bz * s.in_batch_b + (m0 + (long long)dy * p.W + dx) * s.in_ld_b + (long long)kc * BKB;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        bok[i] = rvalid[i] && (unsigned)(ry[i] + dy) < (unsigned)p.H && (unsigned)(rx[i] + dx) < (unsigned)p.W;
+    };
+    auto advance = [&]() {
+      if (++ti >= ntaps_l[sg]) {
+        ti = 0;
+        if (++kc >= nkc) {
+          kc = 0;
+          ++sg;
+          while (ntaps_l[sg] == 0) ++sg;
+          nkc = p.seg[sg].ck_b / BKB;
+          setup_seg();
+        }
+      }
+      setup_tap();
+    };
+    const char* zsrc = reinterpret_cast<const char*>(pp_zero_page) + ((lane & 7) << 4);
+    char* const sa_w = smem + wave * 1024;            // + i * 4096: this wavefront's pieces of the weight tile
+    char* const sb_w = smem + 128 * 128 + wave * 1024;
+    const char* const sa = smem;
+    const char* const sb = smem + 128 * 128;
+    const int frow = lane & 15, fg = lane >> 4;
+
+    setup_seg();
+    setup_tap();
+    for (int st = 0; st < total; ++st) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) glds16(abase + aoff[i], sa_w + i * 4096);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) glds16(bok[i] ? bbase + boff[i] : zsrc, sb_w + i * 4096);
+      if (st + 1 < total) advance();   // address arithmetic of the next step under the loads
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 fb[MJ];
+#pragma unroll
+        for (int j = 0; j < MJ; ++j)
+          fb[j] = *reinterpret_cast<const u32x4*>(sb + tile_off<BKB>(wc * (MJ * 16) + j * 16 + frow, ks * 4 + fg));
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const u32x4 fa = *reinterpret_cast<const u32x4*>(sa + tile_off<BKB>(wr * (MI * 16) + i * 16 + frow, ks * 4 + fg));
+#pragma unroll
+          for (int j = 0; j < MJ; ++j) Mma<bf16_t>::run(fa, fb[j], acc[i][j]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  conv_epilogue<TO, G>(p, acc, smem, wr, wc, lane, tid, co0, m0, mt, bz);
+}
+
+template <typename TO>
+static int launch_dma(ConvDev& d, hipStream_t st, int batch = 1) {
+  d.n_tiles = ceil_div(d.Cout, TileSmall::BCO);
+  const long long blocks = ((d.M - d.m_begin + TileSmall::BPX - 1) / TileSmall::BPX) * d.n_tiles;
+  if (blocks >= 2147483647LL) {
+    set_error("conv: too many tiles");
+    return SEGK_INVALID_ARG;
+  }
+  conv_fwd_dma_kernel<TO><<<dim3((unsigned)blocks, (unsigned)batch), 256, DM_LDS, st>>>(d);
+  return SEGK_OK;
+}
+
+// default for bf16 operands with 128-byte K rows; SEGK_CONV_DMA=0 falls back to the register-staged small tile
+static bool use_dma() {
+  static const char* e = getenv("SEGK_CONV_DMA");
+  return !(e && e[0] == '0');
+}
+
 template <typename TO, int ABL = 0>
 static int launch_pipe(ConvDev& d, hipStream_t st, int batch = 1) {
   static bool configured = false;  // per instantiation
@@ -1047,8 +1227,8 @@ static bool use_big_tile(const ConvDev& d, bool wide, int batch = 1) {
   if (force && (force[0] == 'b' || force[0] == 'h')) return true;
   // Rounds of workgroups each geometry needs (a last round under 15 % full is not counted: the CUs drift apart
   // enough to absorb it, and the big tile hands such a remainder to a small-tile launch anyway).  One workgroup of
-  // the big tile per CU, two of the small one; a round of small tiles takes 0.63 of a round of big ones (measured
-  // on the ASPP convolutions), and covers a quarter of the output per workgroup.
+  // the big tile per CU, three of the small (LDS-DMA) one; a round of small tiles takes 0.77 of a round of big ones
+  // (measured on the decoder convolutions), and covers a quarter of the output per workgroup.
   const long long tiles = ((d.M + TileBig::BPX - 1) / TileBig::BPX) * (d.Cout / TileBig::BCO) * batch;
   const double cus = cu_count();
   auto rounds = [](double r) {
@@ -1056,7 +1236,7 @@ static bool use_big_tile(const ConvDev& d, bool wide, int batch = 1) {
     const double n = whole + (r - whole > 0.15 ? 1.0 : 0.0);
     return n < 1.0 ? 1.0 : n;
   };
-  return rounds(tiles / cus) < 0.63 * rounds(4.0 * tiles / (2.0 * cus));
+  return rounds(tiles / cus) < 0.77 * rounds(4.0 * tiles / (3.0 * cus));
 }
 
 // Tile plan of one forward launch.  With one 256 x 256 workgroup per CU a problem of T tiles takes ceil(T / CUs)
@@ -1198,6 +1378,12 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
 #define SEGK_LAUNCH(T, TO)                                                          \
   (big ? launch_fwd<T, 128, TO, TileBig>(d, st, batch)                              \
        : (wide ? launch_fwd<T, 128, TO, TileSmall>(d, st, batch) : launch_fwd<T, 64, TO, TileSmall>(d, st, batch)))
+  if (a->dtype == SEGK_BF16 && wide && !big && use_dma()) {
+    rc = a->out_dtype == SEGK_BF16 ? launch_dma<bf16_t>(d, st, batch) : launch_dma<float>(d, st, batch);
+    if (rc != SEGK_OK) return rc;
+    SEGK_CHECK_LAUNCH("conv_fwd");
+    return SEGK_OK;
+  }
   if (plan.tail) {
     // whole rounds on the big tile, the remainder on the small one
 #define SEGK_SPLIT(T, TO)                                                               \
@@ -1207,7 +1393,8 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
       SEGK_CHECK_LAUNCH("conv_fwd");                                                    \
       d.m_begin = plan.main_tiles * TileBig::BPX;                                       \
       d.stat_row0 = plan.main_tiles;                                                    \
-      rc = launch_fwd<T, 128, TO, TileSmall>(d, st, 1);                                 \
+      rc = (sizeof(T) == 2 && use_dma()) ? launch_dma<TO>(d, st, 1)                     \
+                                         : launch_fwd<T, 128, TO, TileSmall>(d, st, 1); \
     }                                                                                   \
   } while (0)
     if (a->dtype == SEGK_BF16) {
