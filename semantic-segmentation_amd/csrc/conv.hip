@@ -939,13 +939,131 @@ __global__ __launch_bounds__(CONV_THREADS * NSUB, NSUB == 1 ? 2 : 1) void conv_w
   }
 }
 
+// Weight gradient, 128 x 128 tile through LDS-DMA (bf16): one 32 KB stage ([64 px][128 co] + [64 px][128 ci])
+// filled by global_load_lds, two barriers per 64-pixel chunk, about 100 VGPRs - three workgroups per CU cover each
+// other's load phases.  Same LDS images, fragments and slab output as conv_wgrad_kernel<bf16, 1>.
+__global__ __launch_bounds__(256, 3) void conv_wgrad_dma_kernel(const WgradDev p) {
+  typedef bf16_t T;
+  constexpr int BP = WgFrag<T>::BP;              // 64 pixels per chunk
+  constexpr int SUB_B = BP * 256;                // 16 KB per operand image
+  constexpr int MI = 4, MJ = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [dout image | in image]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  int b = blockIdx.x;
+  const int cot = b % p.co_tiles; b /= p.co_tiles;
+  const int cit = b % p.ci_tiles; b /= p.ci_tiles;
+  const int taps = p.R * p.R;
+  const int tap = b % taps;
+  const int sp = b / taps;
+  const int co0 = cot * TILE, ci0 = cit * TILE;
+  const int dy = (tap / p.R - (p.R >> 1)) * p.dil, dx = (tap % p.R - (p.R >> 1)) * p.dil;
+  const long long pbeg = (long long)sp * p.per_split;
+  long long pend = pbeg + p.per_split;
+  if (pend > p.M) pend = p.M;
+  const int nchunks = pbeg < pend ? (int)((pend - pbeg + BP - 1) / BP) : 0;
+  const long long bz = blockIdx.y;
+
+  // loader geometry: piece q = i*4 + wave (i = 0..3) covers image rows (pixels) q*4 .. q*4+3; lane l -> row
+  // q*4 + (l>>4), LDS slot l&15 of that row, which holds the source chunk the granule swizzle assigns to it
+  const int lr4 = lane >> 4, slot = lane & 15;
+  int lrow[4], csrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    lrow[i] = (i * 4 + wave) * 4 + lr4;
+    const int f = (lrow[i] & 3) | ((lrow[i] >> 1) & 4);
+    csrc[i] = ((((slot >> 1) ^ f) & 7) << 1) | (slot & 1);   // inverse of wg_chunk_off<bf16_t>
+  }
+  const char* dbase = p.dout + bz * p.dout_batch_b + (size_t)co0 * 2;
+  const char* xbase = p.in + bz * p.in_batch_b + (size_t)ci0 * 2;
+  const char* zsrc = reinterpret_cast<const char*>(pp_zero_page) + (slot << 4);
+
+  f32x4 acc[MI][MJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool wave_live = ci0 + wc * 64 < p.Cin && co0 + wr * 64 < p.Cout;
+  char* const sd_w = smem + wave * 1024;            // + i * 4096
+  char* const sx_w = smem + SUB_B + wave * 1024;
+
+  for (int ck = 0; ck < nchunks; ++ck) {
+    int any = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long m = pbeg + (long long)ck * BP + lrow[i];
+      const char* ds = zsrc;
+      const char* xs = zsrc;
+      if (m < pend) {
+        const int rem = pixel_in_image(m, p.HW);
+        const int y = rem / p.W, x = rem - y * p.W;
+        if ((unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W) {
+          any = 1;
+          if (co0 + csrc[i] * 8 < p.Cout) ds = dbase + m * p.dout_ld_b + csrc[i] * 16;
+          if (ci0 + csrc[i] * 8 < p.Cin) xs = xbase + (m + (long long)dy * p.W + dx) * p.in_ld_b + csrc[i] * 16;
+        }
+      }
+      glds16(ds, sd_w + i * 4096);
+      glds16(xs, sx_w + i * 4096);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int cur_any = __syncthreads_or(any);
+    if (cur_any && wave_live) {
+      const char* sd = smem;
+      const char* sx = smem + SUB_B;
+#pragma unroll
+      for (int ks = 0; ks < WgFrag<T>::KSTEPS; ++ks) {
+        u32x4 fb[MJ];
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) fb[j] = WgFrag<T>::read(sx, ks, wc * 64 + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const u32x4 fa = WgFrag<T>::read(sd, ks, wr * 64 + i * 16, lane);
+#pragma unroll
+          for (int j = 0; j < MJ; ++j) WgFrag<T>::mma(fa, fb[j], acc[i][j]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  const int fq = lane >> 4, fr = lane & 15;
+  float* slab = p.slabs + (((size_t)bz * p.splits + sp) * taps + tap) * p.Cin * p.Cout;
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) {
+    const int ci = ci0 + wc * 64 + j * 16 + fr;
+    if (ci >= p.Cin) continue;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int co = co0 + wr * 64 + i * 16 + fq * 4;
+      if (co >= p.Cout) continue;
+      *reinterpret_cast<f32x4*>(slab + (size_t)ci * p.Cout + co) = acc[i][j];
+    }
+  }
+}
+
 // Launch the weight-gradient kernel; the 256 x 256 tile is used when the output channels fill it exactly.
 template <typename T>
 static int launch_wgrad(WgradDev& d, int batch, hipStream_t st, const char* name) {
-  static const char* force = getenv("SEGK_WGRAD_TILE");  // experiments: "small" / "big"
-  // a partial last input-channel tile wastes MFMA work but not loads, and loads are what bounds this kernel
-  bool big = d.Cin >= 256 && d.Cout % 256 == 0;
+  static const char* force = getenv("SEGK_WGRAD_TILE");  // experiments: "small" (register-staged 128 tile) / "big"
+  // The 256 x 256 tile when the output channels fill it exactly and the last input-channel tile is more than half
+  // full (320 input channels would run a second tile that is a quarter full); otherwise the 128 x 128 tile, for
+  // bf16 the LDS-DMA one.
+  bool big = d.Cin >= 256 && d.Cout % 256 == 0 && (d.Cin % 256 == 0 || d.Cin % 256 > 128);
   if (force && force[0] == 's') big = false;
+  if (force && force[0] == 'b') big = d.Cin >= 256 && d.Cout % 256 == 0;
+  if (sizeof(T) == 2 && !big && !(force && force[0] == 's')) {
+    d.co_tiles = ceil_div(d.Cout, TILE);
+    d.ci_tiles = ceil_div(d.Cin, TILE);
+    const long long nb = (long long)d.co_tiles * d.ci_tiles * d.R * d.R * d.splits;
+    if (nb >= 2147483647LL) {
+      set_error("%s: too many tiles", name);
+      return SEGK_INVALID_ARG;
+    }
+    conv_wgrad_dma_kernel<<<dim3((unsigned)nb, (unsigned)batch), 256, 2 * 16384, st>>>(d);
+    return SEGK_OK;
+  }
   const int tch = big ? 2 * TILE : TILE;
   d.co_tiles = ceil_div(d.Cout, tch);
   d.ci_tiles = ceil_div(d.Cin, tch);

@@ -213,11 +213,12 @@ def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=Fals
 
 def default_splits(M, Cin, Cout, R, dtype):
     """Parts of the pixel range so that the launch fills the chip: the 256x256-tile kernel (Cout a multiple of 256,
-    Cin at least 256) runs one workgroup per CU, the 128x128 one two."""
-    big = Cin >= 256 and Cout % 256 == 0
+    Cin at least 256 with a last tile more than half full) runs one workgroup per CU, the 128x128 one two (fp32) or
+    three (bf16, LDS-DMA)."""
+    big = Cin >= 256 and Cout % 256 == 0 and (Cin % 256 == 0 or Cin % 256 > 128)
     t = 256 if big else 128
     tiles = ((Cin + t - 1) // t) * ((Cout + t - 1) // t) * R * R
-    target = 256 if big else 1024
+    target = 256 if big else (768 if dtype == torch.bfloat16 else 1024)
     bp = 64 if dtype == torch.bfloat16 else 32
     chunks = max(1, (M + bp - 1) // bp)
     return max(1, min(target // tiles if tiles <= target else 1, 64, chunks // 8 if chunks >= 8 else 1))
