@@ -1125,12 +1125,13 @@ static int launch_fwd(ConvDev& d, hipStream_t st, int batch = 1, long long px_ti
 // inside a workgroup on purpose: with ~100 VGPRs and 32 KB of LDS three to four workgroups share a CU, and while
 // one waits for its loads the others multiply.
 // ------------------------------------------------------------------------------------------------
-constexpr int DM_LDS = 2 * 128 * 128;
+// PX = pixels per tile: 128 (wave tile 64 x 64, three workgroups per CU) or 256 (64 x 128, two per CU)
 
-template <typename TO>
-__global__ __launch_bounds__(256, 3) void conv_fwd_dma_kernel(const ConvDev p) {
-  typedef TileSmall G;
+template <typename TO, int PX>
+__global__ __launch_bounds__(256, PX == 128 ? 3 : 2) void conv_fwd_dma_kernel(const ConvDev p) {
+  typedef TileCfg<128, PX, 2, 2> G;
   constexpr int BKB = 128, MI = G::MI, MJ = G::MJ;
+  constexpr int NB = PX / 32;   // activation pieces per wavefront
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [A 128 rows][B 128 rows] x 128 B, swizzled
   __shared__ int taps_l[SEGK_MAX_SEG * 9];
   __shared__ int ntaps_l[SEGK_MAX_SEG];
@@ -1149,13 +1150,16 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_dma_kernel(const ConvDev p) {
   // LDS slot l&7, which holds source chunk (l&7) ^ (row&7)
   const int lrow = lane >> 3;
   const int lchunk = ((lane & 7) ^ lrow) << 4;
-  int wrow[4], ry[4], rx[4];
-  bool rvalid[4];
+  int wrow[4], ry[NB], rx[NB];
+  bool rvalid[NB];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int r = (i * 4 + wave) * 8 + lrow;
-    const int co = co0 + r;
+    const int co = co0 + (i * 4 + wave) * 8 + lrow;
     wrow[i] = (co < p.Cout ? co : p.Cout - 1) - co0;
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int r = (i * 4 + wave) * 8 + lrow;
     const long long m = m0 + r;
     rvalid[i] = m < p.M;
     const int rem = pixel_in_image(rvalid[i] ? m : 0, p.HW);
@@ -1173,7 +1177,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_dma_kernel(const ConvDev p) {
         const int dy = (tap / R - (R >> 1)) * dil, dx = (tap % R - (R >> 1)) * dil;
         bool any = false;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NB; ++i)
           any |= rvalid[i] && (unsigned)(ry[i] + dy) < (unsigned)p.H && (unsigned)(rx[i] + dx) < (unsigned)p.W;
         if (any) mine |= 1ull << (sg * 9 + tap);
       }
@@ -1207,17 +1211,16 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_dma_kernel(const ConvDev p) {
     int sg = 0;
     while (ntaps_l[sg] == 0) ++sg;
     int ti = 0, kc = 0, nkc = p.seg[sg].ck_b / BKB;
-    unsigned aoff[4], boff[4];
-    bool bok[4];
+    unsigned aoff[4], boff[NB];
+    bool bok[NB];
     const char* abase = nullptr;
     const char* bbase = nullptr;
     auto setup_seg = [&]() {
       const SegDev& s = p.seg[sg];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        aoff[i] = (unsigned)wrow[i] * (unsigned)s.w_ld_b + lchunk;
-        boff[i] = (unsigned)((i * 4 + wave) * 8 + lrow) * (unsigned)s.in_ld_b + lchunk;
-      }
+      for (int i = 0; i < 4; ++i) aoff[i] = (unsigned)wrow[i] * (unsigned)s.w_ld_b + lchunk;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) boff[i] = (unsigned)((i * 4 + wave) * 8 + lrow) * (unsigned)s.in_ld_b + lchunk;
     };
     auto setup_tap = [&]() {
       const SegDev& s = p.seg[sg];
@@ -1228,7 +1231,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_dma_kernel(const ConvDev p) {
       abase = s.w + bz * s.w_batch_b + (long long)tap * s.w_tap_b + (long long)co0 * s.w_ld_b + (long long)kc * BKB;
       bbase = s.in + bz * s.in_batch_b + (m0 + (long long)dy * p.W + dx) * s.in_ld_b + (long long)kc * BKB;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NB; ++i)
         bok[i] = rvalid[i] && (unsigned)(ry[i] + dy) < (unsigned)p.H && (unsigned)(rx[i] + dx) < (unsigned)p.W;
     };
     auto advance = [&]() {
@@ -1257,7 +1260,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_dma_kernel(const ConvDev p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) glds16(abase + aoff[i], sa_w + i * 4096);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) glds16(bok[i] ? bbase + boff[i] : zsrc, sb_w + i * 4096);
+      for (int i = 0; i < NB; ++i) glds16(bok[i] ? bbase + boff[i] : zsrc, sb_w + i * 4096);
       if (st + 1 < total) advance();   // address arithmetic of the next step under the loads
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -1281,16 +1284,32 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_dma_kernel(const ConvDev p) {
   conv_epilogue<TO, G>(p, acc, smem, wr, wc, lane, tid, co0, m0, mt, bz);
 }
 
-template <typename TO>
-static int launch_dma(ConvDev& d, hipStream_t st, int batch = 1) {
-  d.n_tiles = ceil_div(d.Cout, TileSmall::BCO);
-  const long long blocks = ((d.M - d.m_begin + TileSmall::BPX - 1) / TileSmall::BPX) * d.n_tiles;
+// px_tiles < 0: every pixel tile from d.m_begin to the end
+template <typename TO, int PX = 128>
+static int launch_dma(ConvDev& d, hipStream_t st, int batch = 1, long long px_tiles = -1) {
+  constexpr int lds = (128 + PX) * 128;
+  static bool configured = false;  // per instantiation
+  if (!configured) {
+    int rc = set_lds(conv_fwd_dma_kernel<TO, PX>, lds, "conv_fwd_dma");
+    if (rc != SEGK_OK) return rc;
+    configured = true;
+  }
+  d.n_tiles = ceil_div(d.Cout, 128);
+  if (px_tiles < 0) px_tiles = (d.M - d.m_begin + PX - 1) / PX;
+  const long long blocks = px_tiles * d.n_tiles;
   if (blocks >= 2147483647LL) {
     set_error("conv: too many tiles");
     return SEGK_INVALID_ARG;
   }
-  conv_fwd_dma_kernel<TO><<<dim3((unsigned)blocks, (unsigned)batch), 256, DM_LDS, st>>>(d);
+  conv_fwd_dma_kernel<TO, PX><<<dim3((unsigned)blocks, (unsigned)batch), 256, lds, st>>>(d);
   return SEGK_OK;
+}
+
+// the 128 x 256 LDS-DMA tile serves the big-tile plan for bf16; SEGK_CONV_BIGDMA=0 brings back the register-staged
+// 256 x 256 tile
+static bool use_bigdma() {
+  static const char* e = getenv("SEGK_CONV_BIGDMA");
+  return !(e && e[0] == '0');
 }
 
 // default for bf16 operands with 128-byte K rows; SEGK_CONV_DMA=0 falls back to the register-staged small tile
@@ -1506,7 +1525,8 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
     // whole rounds on the big tile, the remainder on the small one
 #define SEGK_SPLIT(T, TO)                                                               \
   do {                                                                                  \
-    rc = launch_fwd<T, 128, TO, TileBig>(d, st, 1, plan.main_tiles);                    \
+    rc = (sizeof(T) == 2 && use_bigdma()) ? launch_dma<TO, 256>(d, st, 1, plan.main_tiles) \
+                                          : launch_fwd<T, 128, TO, TileBig>(d, st, 1, plan.main_tiles); \
     if (rc == SEGK_OK) {                                                                \
       SEGK_CHECK_LAUNCH("conv_fwd");                                                    \
       d.m_begin = plan.main_tiles * TileBig::BPX;                                       \
@@ -1521,6 +1541,8 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
       if (a->out_dtype == SEGK_BF16) SEGK_SPLIT(float, bf16_t); else SEGK_SPLIT(float, float);
     }
 #undef SEGK_SPLIT
+  } else if (a->dtype == SEGK_BF16 && big && use_bigdma()) {
+    rc = a->out_dtype == SEGK_BF16 ? launch_dma<bf16_t, 256>(d, st, batch) : launch_dma<float, 256>(d, st, batch);
   } else if (a->dtype == SEGK_BF16 && big && use_pipe()) {
     rc = a->out_dtype == SEGK_BF16 ? launch_pipe<bf16_t>(d, st, batch) : launch_pipe<float>(d, st, batch);
   } else if (a->dtype == SEGK_BF16) {
@@ -1616,6 +1638,8 @@ extern "C" int segk_gemm_nt(const segk_gemm_args* a, segk_stream_t stream) {
   d.bias = nullptr; d.img_bias = nullptr; d.stat = nullptr;
   const long long big_tiles = (long long)ceil_div(a->M, TileBig::BPX) * (a->N / TileBig::BCO) * a->batch;
   const bool big = wide && a->N % TileBig::BCO == 0 && big_tiles >= 512;
+  static const char* gemm_env = getenv("SEGK_GEMM_DMA");
+  const bool gemm_dma = !(gemm_env && gemm_env[0] == '0');
   hipStream_t st = (hipStream_t)stream;
   int rc;
 #define SEGK_LAUNCH(T, TO)                                                                   \
@@ -1623,6 +1647,10 @@ extern "C" int segk_gemm_nt(const segk_gemm_args* a, segk_stream_t stream) {
        : (wide ? launch_fwd<T, 128, TO, TileSmall>(d, st, a->batch) : launch_fwd<T, 64, TO, TileSmall>(d, st, a->batch)))
   if (a->dtype == SEGK_BF16 && big && use_pipe()) {
     rc = a->c_dtype == SEGK_BF16 ? launch_pipe<bf16_t>(d, st, a->batch) : launch_pipe<float>(d, st, a->batch);
+  } else if (a->dtype == SEGK_BF16 && big && use_bigdma() && gemm_dma) {
+    rc = a->c_dtype == SEGK_BF16 ? launch_dma<bf16_t, 256>(d, st, a->batch) : launch_dma<float, 256>(d, st, a->batch);
+  } else if (a->dtype == SEGK_BF16 && wide && !big && use_dma() && gemm_dma) {
+    rc = a->c_dtype == SEGK_BF16 ? launch_dma<bf16_t>(d, st, a->batch) : launch_dma<float>(d, st, a->batch);
   } else if (a->dtype == SEGK_BF16) {
     rc = a->c_dtype == SEGK_BF16 ? SEGK_LAUNCH(bf16_t, bf16_t) : SEGK_LAUNCH(bf16_t, float);
   } else {
