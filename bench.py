@@ -116,18 +116,22 @@ def cpu_baseline(args):
                       % (args.out_stride, args.classes, args.cpu_batch, args.size, args.size, sec)}
 
 
-def measured_traffic(args, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes (tools/pmc_traffic.sh: one
-    FETCH_SIZE pass and one WRITE_SIZE pass over this same bench command, FETCH_SIZE doubled as gfx950 requires).
-    Counters cannot be collected from inside a timed run, so the figure is read from profiles/; it applies to
-    the default workload only."""
+def measured_traffic(args, families, calls_per_step):
+    """HBM bytes per library call of the kernel `families` from the committed rocprofv3 counter passes
+    (tools/pmc_traffic.sh: one FETCH_SIZE pass and one WRITE_SIZE pass over this same bench command, FETCH_SIZE
+    doubled as gfx950 requires).  A call may be more than one launch (main + tail), so the launches' bytes are
+    summed and divided by the calls of the profiled steps.  Counters cannot be collected from inside a timed run,
+    so the figure is read from profiles/; it applies to the default workload only."""
     default = (args.batch, args.size, args.classes, args.out_stride, args.dtype) == (16, 513, 21, 16, "bf16")
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not default or not os.path.exists(path):
+    if not default or not os.path.exists(path) or calls_per_step <= 0:
         return None
     try:
         with open(path) as f:
-            return float(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"])
+            doc = json.load(f)
+        total = sum(float(doc["kernels"][k]["launches"]) * float(doc["kernels"][k]["hbm_bytes_per_launch"])
+                    for k in families if k in doc["kernels"])
+        return total / (float(doc.get("bench_steps", 3)) * calls_per_step) if total > 0 else None
     except (KeyError, ValueError, OSError):
         return None
 
@@ -258,11 +262,14 @@ def main():
                 peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MATRIX_PEAK_TFLOPS
                 ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
                 line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                                    "frac": ach / peak, "traffic": measured_traffic(args, "conv_fwd_kernel"),
-                                    "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
-                                                    "profiles/pmc_traffic.json)",
-                                    "kernel": "conv_fwd_kernel (implicit-GEMM "
-                                    "forward + data gradient, all %d launches of the timed steps)" % dom["launches"],
+                                    "frac": ach / peak,
+                                    "traffic": measured_traffic(args, ("conv_fwd_dma_kernel", "conv_fwd_kernel"),
+                                                                dom["launches"] / float(args.steps)),
+                                    "traffic_unit": "HBM bytes per segk_conv_fwd call (rocprofv3 FETCH_SIZE x2 + "
+                                                    "WRITE_SIZE, profiles/pmc_traffic.json)",
+                                    "kernel": "conv_fwd_dma_kernel / conv_fwd_kernel (implicit-GEMM forward + data "
+                                    "gradient, all %d segk_conv_fwd calls of the timed steps; a call is one launch or "
+                                    "a main + tail pair)" % dom["launches"],
                                     "avg_launch_ms": dom["avg_ms"],
                                     "share_of_step": dom["ms"] / (1000.0 * elapsed)}
             wg = conv_summ.get("conv_wgrad_kernel")
@@ -271,6 +278,7 @@ def main():
                 ach = wg["flops"] / (wg["ms"] * 1e-3) / 1e12
                 line["roofline_wgrad"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                                           "frac": ach / peak, "avg_launch_ms": wg["avg_ms"],
+                                          "kernel": "conv_wgrad_kernel / conv_wgrad_dma_kernel (%d calls)" % wg["launches"],
                                           "share_of_step": wg["ms"] / (1000.0 * elapsed)}
             bn = [v for k, v in summ.items() if k.startswith("bn_")]
             if bn:

@@ -1140,8 +1140,16 @@ __global__ __launch_bounds__(256, PX == 128 ? 3 : 2) void conv_fwd_dma_kernel(co
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave / G::WPX, wc = wave % G::WPX;
-  const int nt = blockIdx.x % p.n_tiles;
-  const long long mt = blockIdx.x / p.n_tiles;
+  // Workgroups go to the eight XCDs round-robin by block index; give each XCD a contiguous run of tiles, so that
+  // the output-channel tiles of one pixel tile and the neighbouring pixel tiles (which share the rows the 3x3 taps
+  // reach into) meet in the same L2.
+  unsigned tile;
+  {
+    const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u, xcd = blockIdx.x & 7u;
+    tile = xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3);
+  }
+  const int nt = tile % p.n_tiles;
+  const long long mt = tile / p.n_tiles;
   const int co0 = nt * G::BCO;
   const long long m0 = p.m_begin + mt * G::BPX;
   const long long bz = blockIdx.y;

@@ -42,7 +42,9 @@ def main():
         wr = write.get(k, 0.0) * 1024.0 / lw
         out[k] = {"launches": nf.get(k, 0), "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                   "hbm_bytes_per_launch": rd + wr}
-    json.dump({"unit": "bytes per launch (FETCH_SIZE x2 x1024, WRITE_SIZE x1024)", "kernels": out}, sys.stdout, indent=1)
+    # tools/pmc_traffic.sh profiles `bench.py --steps 2 --warmup 1`: three steps
+    json.dump({"unit": "bytes per launch (FETCH_SIZE x2 x1024, WRITE_SIZE x1024)", "bench_steps": 3, "kernels": out},
+              sys.stdout, indent=1)
 
 
 if __name__ == "__main__":
