@@ -825,7 +825,13 @@ __global__ __launch_bounds__(CONV_THREADS * NSUB, NSUB == 1 ? 2 : 1) void conv_w
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = NSUB == 1 ? wave >> 1 : wave >> 2;   // co block of MI*16 channels
   const int wc = NSUB == 1 ? wave & 1 : wave & 3;     // ci block of 64 channels
-  int b = blockIdx.x;
+  // each XCD (workgroups go to them round-robin by block index) gets a contiguous run of tiles: the tiles and taps
+  // of one pixel range, which read the same rows of both operands, then share an L2
+  int b;
+  {
+    const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u, xcd = blockIdx.x & 7u;
+    b = (int)(xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3));
+  }
   const int cot = b % p.co_tiles; b /= p.co_tiles;
   const int cit = b % p.ci_tiles; b /= p.ci_tiles;
   const int taps = p.R * p.R;
@@ -951,7 +957,13 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_dma_kernel(const WgradDev p
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  int b = blockIdx.x;
+  // each XCD (workgroups go to them round-robin by block index) gets a contiguous run of tiles: the tiles and taps
+  // of one pixel range, which read the same rows of both operands, then share an L2
+  int b;
+  {
+    const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u, xcd = blockIdx.x & 7u;
+    b = (int)(xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3));
+  }
   const int cot = b % p.co_tiles; b /= p.co_tiles;
   const int cit = b % p.ci_tiles; b /= p.ci_tiles;
   const int taps = p.R * p.R;
