@@ -1058,13 +1058,14 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_dma_kernel(const WgradDev p
 // Launch the weight-gradient kernel; the 256 x 256 tile is used when the output channels fill it exactly.
 template <typename T>
 static int launch_wgrad(WgradDev& d, int batch, hipStream_t st, const char* name) {
-  static const char* force = getenv("SEGK_WGRAD_TILE");  // experiments: "small" (register-staged 128 tile) / "big"
+  static const char* force = getenv("SEGK_WGRAD_TILE");  // experiments: "small" (register-staged 128 tile) / "big" / "dma"
   // The 256 x 256 tile when the output channels fill it exactly and the last input-channel tile is more than half
   // full (320 input channels would run a second tile that is a quarter full); otherwise the 128 x 128 tile, for
   // bf16 the LDS-DMA one.
   bool big = d.Cin >= 256 && d.Cout % 256 == 0 && (d.Cin % 256 == 0 || d.Cin % 256 > 128);
   if (force && force[0] == 's') big = false;
   if (force && force[0] == 'b') big = d.Cin >= 256 && d.Cout % 256 == 0;
+  if (force && force[0] == 'd') big = false;   // "dma": the 128 x 128 LDS-DMA tile everywhere (bf16)
   if (sizeof(T) == 2 && !big && !(force && force[0] == 's')) {
     d.co_tiles = ceil_div(d.Cout, TILE);
     d.ci_tiles = ceil_div(d.Cin, TILE);
