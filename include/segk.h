@@ -288,6 +288,17 @@ int segk_ce_partial_rows(long long pixels);
 int segk_ce_bwd(const float* logits, const float* target, const float* weight, const float* lse, int N, int K,
                 int HW, int ignore_index, const float* coef_dev, float* dlogits, segk_stream_t stream);
 
+/* segk_ce_fwd for callers that cannot allocate device memory or carry a workspace (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.
+ * The partial rows live in a fixed 16 KiB device array inside the library (one copy per GPU, held until the
+ * process ends); the call allocates nothing.  Same results as segk_ce_fwd, bit for bit.  At most
+ * segk_ce_fwd_static_max_pixels() = 2^25 pixels (N*HW); more returns SEGK_UNSUPPORTED_SHAPE.  All calls on one
+ * GPU share that array: calls that overlap on one GPU (two streams, two threads) race; calls ordered on one
+ * stream do not. */
+int segk_ce_fwd_static(const float* logits, const float* target, const float* weight, int N, int K, int HW,
+                       int ignore_index, float* lse, float* sums, segk_stream_t stream);
+long long segk_ce_fwd_static_max_pixels(void);
+
 /* Final upsample (modeling/deeplab.py:252) fused with the cross entropy (utils/loss.py:23-35): the loss of
  * F.interpolate(low, (Ho,Wo), bilinear, align_corners=True) without writing the full-resolution logits.
  * low: pixel-major fp32 [N*Hi*Wi][low_ld], K classes; target fp32 [N][Ho][Wo]; lse, partials, sums as segk_ce_fwd

@@ -3,6 +3,8 @@
 // planes, so every wavefront access is a contiguous run of one plane.
 #include <math.h>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace segk {
@@ -198,6 +200,65 @@ extern "C" int segk_ce_fwd(const float* logits, const float* target, const float
   ce_fwd_kernel<<<rows, CE_THREADS, 0, st>>>(logits, target, weight, K, HW, P, ignore_index, lse, partials);
   SEGK_CHECK_LAUNCH("ce_fwd");
   ce_finish_kernel<<<1, 256, 0, st>>>(partials, rows, sums);
+  SEGK_CHECK_LAUNCH("ce_finish");
+  return SEGK_OK;
+}
+
+// ---- segk_ce_fwd without any allocation ---------------------------------------------------------------
+// The partial rows of segk_ce_fwd live in a file-scope device array instead of a caller workspace.  Every GPU
+// the library runs on holds its own copy at its own address, found once per device with hipGetSymbolAddress
+// (host code never passes the array's name to a kernel).
+constexpr long long CE_STATIC_MAX_PIXELS = 1ll << 25;  // <= 64 pixels per thread of the 2048 x 256 grid
+static __device__ __align__(256) float scratch[2 * CE_MAX_ROWS];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+float* g_scratch_ptr[MAX_DEVICES] = {};
+
+// Address of this device's copy of `scratch` (looked up on the first call per device, under a mutex).
+int scratch_for_current_device(float** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
+    set_error("ce_fwd_static: hipGetDevice: %s (device %d)", hipGetErrorString(e), dev);
+    return SEGK_HIP_ERROR;
+  }
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) {
+      set_error("ce_fwd_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+      return SEGK_HIP_ERROR;
+    }
+    g_scratch_ptr[dev] = (float*)p;
+  }
+  *out = g_scratch_ptr[dev];
+  return SEGK_OK;
+}
+}  // namespace
+
+extern "C" long long segk_ce_fwd_static_max_pixels(void) { return CE_STATIC_MAX_PIXELS; }
+
+extern "C" int segk_ce_fwd_static(const float* logits, const float* target, const float* weight, int N, int K, int HW,
+                                  int ignore_index, float* lse, float* sums, segk_stream_t stream) {
+  SEGK_REQUIRE(logits && target && lse && sums, "ce_fwd_static: null pointer");
+  SEGK_REQUIRE(N > 0 && K > 0 && HW > 0, "ce_fwd_static: bad shape N=%d K=%d HW=%d", N, K, HW);
+  const long long P = (long long)N * HW;
+  SEGK_UNSUPPORTED(P <= CE_STATIC_MAX_PIXELS,
+                   "ce_fwd_static: %lld pixels exceed the %lld this entry point's fixed scratch serves; use "
+                   "segk_ce_fwd with a caller workspace", P, CE_STATIC_MAX_PIXELS);
+  float* part = nullptr;
+  const int rc = scratch_for_current_device(&part);
+  if (rc != SEGK_OK) return rc;
+  const int rows = ce_rows(P);
+  hipStream_t st = (hipStream_t)stream;
+  // every row below `rows` is overwritten by its workgroup and the finish kernel reads only those rows, so the
+  // previous call's contents need no clearing
+  ce_fwd_kernel<<<rows, CE_THREADS, 0, st>>>(logits, target, weight, K, HW, P, ignore_index, lse, part);
+  SEGK_CHECK_LAUNCH("ce_fwd_static");
+  ce_finish_kernel<<<1, 256, 0, st>>>(part, rows, sums);
   SEGK_CHECK_LAUNCH("ce_finish");
   return SEGK_OK;
 }

@@ -99,6 +99,8 @@ SIGNATURES = {
     "segk_ce_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                     c_void_p],
     "segk_ce_partial_rows": [c_ll],
+    "segk_ce_fwd_static": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "segk_ce_fwd_static_max_pixels": [],
     "segk_ce_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                     c_void_p],
     "segk_argmax": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
@@ -117,7 +119,8 @@ SIGNATURES = {
     "segk_allreduce_i64": [c_void_p, c_ll, c_void_p],
     "segk_sgd_step": [c_void_p, c_int, c_float, c_float, c_float, c_void_p],
 }
-_RESTYPES = {"segk_last_error": ctypes.c_char_p, "segk_upsample_bwd_workspace": c_ll}
+_RESTYPES = {"segk_last_error": ctypes.c_char_p, "segk_upsample_bwd_workspace": c_ll,
+             "segk_ce_fwd_static_max_pixels": c_ll}
 
 _lib = None
 
