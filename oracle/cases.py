@@ -21,7 +21,7 @@ class Impl:
 
     def __init__(self, Branch, ASPP, Decoder, ce_loss, Evaluator, DeepLab=None, BatchNorm=nn.BatchNorm2d,
                  interpolate=None, lr_groups=None, device="cpu", name="impl", PAM=None, CAM=None, DAMM=None,
-                 DeepLabDAMM=None):
+                 DeepLabDAMM=None, focal_loss=None, class_weights=None, optimizer=None, scheduler=None):
         self.Branch = Branch          # (inplanes, planes, k, padding, dilation, BatchNorm)
         self.ASPP = ASPP              # (backbone, output_stride, BatchNorm)
         self.Decoder = Decoder        # (num_classes, backbone, BatchNorm)
@@ -38,6 +38,13 @@ class Impl:
         self.CAM = CAM                # (in_dim)
         self.DAMM = DAMM              # (backbone, BatchNorm)
         self.DeepLabDAMM = DeepLabDAMM  # () -> module (R101 / OS16 / K=8)
+        self.focal_loss = focal_loss  # (logit, target, weight) -> scalar tensor
+        self.class_weights = class_weights  # (dataset name, iterable of {'label': tensor}, num_classes) -> [K] float64
+        # (param groups, momentum=, weight_decay=, nesterov=) -> optimizer; None: torch.optim.SGD
+        self.optimizer = optimizer
+        # (mode, base_lr, num_epochs, iters_per_epoch) -> callable(optimizer, i, epoch, best_pred); None: the poly
+        # formula written out in case_e2e
+        self.scheduler = scheduler
 
 
 def _t(a, device, grad=False):
@@ -200,6 +207,45 @@ def case_ce(impl, name, K):
     return {"loss": _np(loss).reshape(1), "dlogit": _np(logit.grad)}
 
 
+FOCAL_CFGS = [("plain", 21), ("one_image_ignored", 21), ("weighted", 21), ("k8", 8)]
+
+
+def case_focal(impl, name, K):
+    """SegmentationLosses(...).build_loss('focal') (/root/reference/utils/loss.py:37-53) on the cross-entropy
+    inputs: value and gradient with respect to the logits."""
+    logit_np, target_np, weight_np = ce_inputs(name, K=K)
+    logit = _t(logit_np, impl.device, grad=True)
+    target = _t(target_np, impl.device)
+    weight = None if weight_np is None else _t(weight_np, impl.device)
+    loss = impl.focal_loss(logit, target, weight)
+    loss.backward()
+    return {"loss": _np(loss).reshape(1), "dlogit": _np(logit.grad)}
+
+
+def class_weight_batches(K, batches=3, n=2, h=40, w=33):
+    """Label batches the way a loader hands them to calculate_weigths_labels
+    (/root/reference/utils/calculate_weights.py:12-19): float maps with 255, negative and too-large labels, and one
+    class that never occurs."""
+    out = []
+    for b in range(batches):
+        tag = "cw_k%d/%d" % (K, b)
+        y = gen.labels(SEED, tag, (n, h, w), K, border=1, ignore_frac=0.15)
+        odd = gen.uniform(SEED, tag + "/odd", (n, h, w))
+        y[odd < 0.02] = -1.0
+        y[(odd >= 0.02) & (odd < 0.04)] = K + 3
+        y[y == 2] = 5.0  # class 2 never occurs: weight 1 / ln(1.02)
+        out.append(y)
+    return out
+
+
+CW_KS = [8, 21]
+
+
+def case_class_weights(impl, K):
+    loader = [{"label": torch.from_numpy(y)} for y in class_weight_batches(K)]
+    return {"weights": np.asarray(impl.class_weights("synthetic", loader, K), dtype=np.float64)}
+
+
 # ----------------------------------------------------------- (6) evaluator ----
 EVAL_KS = [8, 19, 21, 81]
 
@@ -245,31 +291,47 @@ def case_e2e(impl, steps=2, n=4, size=65, K=21, base_lr=0.007, total_iters=100):
     _zero_dropout(model)
     model.train()
     g1, g10 = impl.lr_groups(model)
-    opt = torch.optim.SGD([{"params": g1, "lr": base_lr}, {"params": g10, "lr": base_lr * 10}],
-                          momentum=0.9, weight_decay=5e-4, nesterov=False)
+    make_opt = impl.optimizer or torch.optim.SGD
+    opt = make_opt([{"params": g1, "lr": base_lr}, {"params": g10, "lr": base_lr * 10}],
+                   momentum=0.9, weight_decay=5e-4, nesterov=False)
+    sched = impl.scheduler("poly", base_lr, 1, total_iters) if impl.scheduler else None
+    names = ("aspp.aspp3.atrous_conv.weight", "aspp.conv1.weight", "decoder.last_conv.0.weight",
+             "decoder.last_conv.8.bias", "aspp.bn1.weight", "aspp.bn1.running_var",
+             "decoder.bn1.running_mean", "backbone.layer4.2.conv2.weight", "backbone.bn1.running_mean")
     out = {}
     losses = []
     for it in range(steps):
         image = _t(gen.normal(SEED, tag + "/img%d" % it, (n, 3, size, size)) * _gain(n), impl.device)
         target = _t(gen.labels(SEED, tag + "/lab%d" % it, (n, size, size), K, border=2), impl.device)
-        lr = base_lr * pow((1 - 1.0 * it / total_iters), 0.9)
-        opt.param_groups[0]["lr"] = lr
-        opt.param_groups[1]["lr"] = lr * 10
+        if sched is not None:
+            sched(opt, it, 0, 0.0)
+        else:
+            lr = base_lr * pow((1 - 1.0 * it / total_iters), 0.9)
+            opt.param_groups[0]["lr"] = lr
+            opt.param_groups[1]["lr"] = lr * 10
         opt.zero_grad()
         output = model(image)
         loss = impl.ce_loss(output, target, None)
         loss.backward()
         opt.step()
         losses.append(float(loss.detach().cpu()))
+        if it == 0:
+            # the first step is a pure function of the inputs: its predictions and the weights it produces are
+            # comparable tightly (later steps inherit the chaotic growth of last-bit differences)
+            ev = impl.Evaluator(K)
+            ev.add_batch(target.cpu().numpy(), np.argmax(_np(output), axis=1))
+            out["cm0"] = np.asarray(ev.confusion_matrix, dtype=np.float64)
+            out["logits0_sample"] = _sample(_np(output), 8192)
+            sd = model.state_dict()
+            for name in names:
+                out["w0/" + name] = _sample(_np(sd[name]), 2048)
     out["losses"] = np.array(losses, dtype=np.float64)
     out["logits_sample"] = _sample(_np(output), 8192)
     ev = impl.Evaluator(K)
     ev.add_batch(target.cpu().numpy(), np.argmax(_np(output), axis=1))
     out["cm"] = np.asarray(ev.confusion_matrix, dtype=np.float64)
     sd = model.state_dict()
-    for name in ("aspp.aspp3.atrous_conv.weight", "aspp.conv1.weight", "decoder.last_conv.0.weight",
-                 "decoder.last_conv.8.bias", "aspp.bn1.weight", "aspp.bn1.running_var",
-                 "decoder.bn1.running_mean", "backbone.layer4.2.conv2.weight", "backbone.bn1.running_mean"):
+    for name in names:
         out["w/" + name] = _sample(_np(sd[name]), 2048)
     return out
 

@@ -38,6 +38,7 @@ def _reset(module):
 # to a tight tolerance the tests hand the activation pattern of the implementation under test to this
 # restatement (forward = x * mask, backward = g * mask); with no pattern set it is the plain F.relu.
 _MASKS = None
+_RECORD = None   # a list: every plain ReLU appends its activation pattern (bool tensor) in call order
 
 
 class _MaskedReLU(torch.autograd.Function):
@@ -54,6 +55,8 @@ class _MaskedReLU(torch.autograd.Function):
 
 def _relu(x):
     if _MASKS is None:
+        if _RECORD is not None:
+            _RECORD.append((x > 0).detach().cpu())
         return F.relu(x)
     m = _MASKS.pop(0)
     assert tuple(m.shape) == tuple(x.shape), (tuple(m.shape), tuple(x.shape))
@@ -77,6 +80,21 @@ class use_relu_masks:
         _MASKS = None
         if exc[0] is None and left:
             raise AssertionError("%d ReLU masks were not consumed" % left)
+
+
+class record_relu_masks:
+    """Context manager: collects the activation pattern of every ReLU the Ref* modules evaluate (call order), so a
+    test can count how many elements another implementation activates differently."""
+
+    def __enter__(self):
+        global _RECORD
+        _RECORD = []
+        self.masks = _RECORD
+        return self
+
+    def __exit__(self, *exc):
+        global _RECORD
+        _RECORD = None
 
 
 class _ReLU(nn.Module):

@@ -8,8 +8,10 @@ implementations whose pre-activations differ in the last bits disagree on the si
 to zero, and ReLU's derivative jumps there, so one flipped element moves a per-channel gradient sum by
 percents regardless of kernel quality.  The tests therefore capture the ReLU pattern the HIP kernels
 produced and hand it to the oracle (oracle.head_ref.use_relu_masks); gradients must then agree to 1e-3
-(fp32) / 2e-2 (bf16).  The fraction of elements whose sign differs from the unconstrained reference is
-asserted to be tiny, and plain (unmatched) gradient agreement is still checked at a coarse level.
+(fp32) / 2e-2 (bf16) in the max norm.  Two further checks keep that honest: the number of elements whose
+activation differs from the unconstrained oracle is counted per ReLU layer and must stay below 1e-4 of the layer
+in fp32 (`flips=True`), and the UNMATCHED gradients are compared with the imported reference's own goldens in the
+L2 norm (`assert_grads_l2`), which a handful of flipped elements cannot dominate: 1e-3 fp32 / 2e-2 bf16.
 """
 import numpy as np
 import pytest
@@ -45,7 +47,12 @@ def segk_impl(bn="torch"):
     def ce(logit, target, weight):
         return SegmentationLosses(weight=weight, cuda=True).build_loss("ce")(logit, target)
 
-    return cases.Impl(Branch=aspp._ASPPModule, ASPP=aspp.build_aspp, Decoder=decoder.build_decoder, ce_loss=ce,
+    def focal(logit, target, weight):
+        return SegmentationLosses(weight=weight, cuda=True).build_loss("focal")(logit, target)
+
+    from segk.utils.calculate_weights import calculate_weigths_labels
+
+    return cases.Impl(focal_loss=focal, class_weights=calculate_weigths_labels, Branch=aspp._ASPPModule, ASPP=aspp.build_aspp, Decoder=decoder.build_decoder, ce_loss=ce,
                       Evaluator=Evaluator,
                       DeepLab=lambda: deeplab.DeepLab("resnet", 16, 21, sync_bn=(bn != "torch")),
                       BatchNorm=BN, interpolate=SF.interpolate_bilinear_ac,
@@ -76,14 +83,80 @@ def run_with_capture(fn):
     return out, masks
 
 
-def matched(case_fn, impl, oracle_device, *args, dtype=torch.float32, **kw):
-    """(HIP result, oracle result on the HIP activation pattern)."""
+FLIP_FRACTION = 1e-4
+FLIPS = {}   # test id -> [(elements, differing activations)] per ReLU layer, printed at the end of the module
+
+
+def count_flips(name, case_fn, masks, oracle_device, *args, bound=FLIP_FRACTION, **kw):
+    """Run the oracle WITHOUT a supplied activation pattern and count, per ReLU layer, the elements the HIP path
+    activated differently; returns the largest per-layer fraction.  With a bound, a layer may differ in that
+    fraction of its elements (never fewer than 2 are allowed, so that a 10 000-element layer of a small case is
+    not failed by one value that is zero to the last bit)."""
+    with head_ref.record_relu_masks() as rec:
+        case_fn(oracle_impl(oracle_device), *args, **kw)
+    assert len(rec.masks) == len(masks), (len(rec.masks), len(masks))
+    rows = []
+    for a, b in zip(masks, rec.masks):
+        assert tuple(a.shape) == tuple(b.shape)
+        rows.append((a.numel(), int((a.cpu() != b).sum())))
+    FLIPS[name] = rows
+    if bound is not None:
+        bad = [(i, n, f) for i, (n, f) in enumerate(rows) if f > max(2, bound * n)]
+        assert not bad, "ReLU layers whose activation pattern differs from the oracle's (layer, elements, flips): %s" % bad
+    return max(f / n for n, f in rows)
+
+
+def matched(case_fn, impl, oracle_device, *args, dtype=torch.float32, flips=None, **kw):
+    """(HIP result, oracle result on the HIP activation pattern[, largest per-layer fraction of activations that
+    differ from the unconstrained oracle's when `flips` names the test]).  In fp32 that fraction is gated at 1e-4;
+    in bf16 (operands rounded to 8 bits: pre-activations within 1e-2 of zero change sign) it is only measured."""
     from segk import config
     with config.compute_dtype_as(dtype):
         got, masks = run_with_capture(lambda: case_fn(impl, *args, **kw))
     with head_ref.use_relu_masks(masks):
         want = case_fn(oracle_impl(oracle_device), *args, **kw)
+    if flips:
+        frac = count_flips(flips, case_fn, masks, oracle_device, *args,
+                           bound=FLIP_FRACTION if dtype == torch.float32 else None, **kw)
+        return got, want, frac
     return got, want
+
+
+L2 = {}   # (test, key) -> (rel_l2 of the unmatched gradient, gate), for the report
+
+
+def assert_grads_l2(name, got, gold, tol, flip_fraction, skip=()):
+    """Unmatched gradients against the imported reference's goldens in the L2 norm.
+
+    A flipped activation changes single gradient elements by their whole value, so with a fraction f of a layer
+    flipped the L2 distance between two CORRECT implementations is about sqrt(f) (f = 2e-6, two dozen elements of
+    the 12.8 M of a 129 x 129 decoder map, already gives 1.4e-3).  The gate is therefore the parity tolerance plus
+    4 sqrt(f) with the f measured in the same test; without flips it is the parity tolerance itself."""
+    gate = tol + 4.0 * flip_fraction ** 0.5
+    bad = []
+    for k, w in gold.items():
+        if not is_grad_key(k) or k in skip:
+            continue
+        e = rel_l2(got[k], w)
+        L2[(name, k)] = (e, gate)
+        if not e <= gate:
+            bad.append((k, e))
+    assert not bad, "unmatched gradients differ from the reference (key, rel_l2; gate %g): %s" % (gate, bad)
+
+
+def teardown_module(module):
+    if FLIPS:
+        print("\nReLU activation differences against the unconstrained oracle (elements, flips) per layer:")
+        for k, rows in FLIPS.items():
+            print("  %-28s %s" % (k, rows))
+    if L2:
+        print("unmatched gradient rel_l2 against the reference goldens (worst key per test):")
+        by = {}
+        for (t, k), (e, gate) in L2.items():
+            if e > by.get(t, ("", -1.0, 0.0))[1]:
+                by[t] = (k, e, gate)
+        for t, (k, e, gate) in by.items():
+            print("  %-28s %-32s %.3e (gate %.3e)" % (t, k, e, gate))
 
 
 @pytest.fixture(scope="module")
@@ -100,16 +173,20 @@ def impl_sync():
 # ---------------------------------------------------------------- branches ----
 @pytest.mark.parametrize("k,d", cases.BRANCH_CFGS)
 def test_branch_fp32(impl, k, d):
-    got, want = matched(cases.case_branch, impl, "cpu", k, d)
-    assert_dicts_close(forward_only(got), forward_only(load_golden("branch_k%d_d%d" % (k, d))), FWD)
+    name = "branch_k%d_d%d" % (k, d)
+    got, want, frac = matched(cases.case_branch, impl, "cpu", k, d, flips=name)
+    assert_dicts_close(forward_only(got), forward_only(load_golden(name)), FWD)
     assert_dicts_close(got, want, FWD, GRAD)
+    assert_grads_l2(name, got, load_golden(name), GRAD, frac)
 
 
 @pytest.mark.parametrize("k,d", [(1, 1), (3, 6), (3, 18)])
 def test_branch_bf16(impl, k, d):
-    got, want = matched(cases.case_branch, impl, "cpu", k, d, dtype=torch.bfloat16)
-    assert_dicts_close(forward_only(got), forward_only(load_golden("branch_k%d_d%d" % (k, d))), BF)
+    name = "branch_k%d_d%d" % (k, d)
+    got, want, frac = matched(cases.case_branch, impl, "cpu", k, d, dtype=torch.bfloat16, flips=name + " bf16")
+    assert_dicts_close(forward_only(got), forward_only(load_golden(name)), BF)
     assert_dicts_close(got, want, BF, BF)
+    assert_grads_l2(name + " bf16", got, load_golden(name), BF, frac)
 
 
 def test_branch_syncbn_class(impl_sync):
@@ -120,36 +197,42 @@ def test_branch_syncbn_class(impl_sync):
 
 # -------------------------------------------------------------------- ASPP ----
 def test_aspp_mobilenet_fp32(impl):
-    got, want = matched(cases.case_aspp, impl, "cpu", "mobilenet", 16)
+    got, want, frac = matched(cases.case_aspp, impl, "cpu", "mobilenet", 16, flips="aspp_mobilenet")
     assert_dicts_close(forward_only(got), forward_only(load_golden("aspp_mobilenet_os16")), FWD)
     assert_dicts_close(got, want, FWD, GRAD)
+    assert_grads_l2("aspp_mobilenet", got, load_golden("aspp_mobilenet_os16"), GRAD, frac)
 
 
 def test_aspp_drn_os8_fp32(impl):
     kw = dict(shape=(4, 13, 9), inplanes=512)
-    got, want = matched(cases.case_aspp, impl, "cpu", "drn", 8, **kw)
+    got, want, frac = matched(cases.case_aspp, impl, "cpu", "drn", 8, flips="aspp_drn_os8", **kw)
     assert_dicts_close(forward_only(got), forward_only(load_golden("aspp_drn_os8")), FWD)
     assert_dicts_close(got, want, FWD, GRAD)
+    assert_grads_l2("aspp_drn_os8", got, load_golden("aspp_drn_os8"), GRAD, frac)
 
 
 def test_aspp_bf16(impl):
-    got, want = matched(cases.case_aspp, impl, "cpu", "mobilenet", 16, dtype=torch.bfloat16)
+    got, want, frac = matched(cases.case_aspp, impl, "cpu", "mobilenet", 16, dtype=torch.bfloat16,
+                              flips="aspp_mobilenet bf16")
     assert_dicts_close(forward_only(got), forward_only(load_golden("aspp_mobilenet_os16")), BF)
     assert_dicts_close(got, want, BF, BF)
+    assert_grads_l2("aspp_mobilenet bf16", got, load_golden("aspp_mobilenet_os16"), BF, frac)
 
 
 # ----------------------------------------------------------------- decoder ----
 @pytest.mark.parametrize("K", [21, 19])
 def test_decoder_fp32(impl, K):
-    got, want = matched(cases.case_decoder, impl, "cpu", K)
+    got, want, frac = matched(cases.case_decoder, impl, "cpu", K, flips="decoder_k%d" % K)
     assert_dicts_close(forward_only(got), forward_only(load_golden("decoder_k%d" % K)), FWD)
     assert_dicts_close(got, want, FWD, GRAD)
+    assert_grads_l2("decoder_k%d" % K, got, load_golden("decoder_k%d" % K), GRAD, frac)
 
 
 def test_decoder_bf16(impl):
-    got, want = matched(cases.case_decoder, impl, "cpu", 21, dtype=torch.bfloat16)
+    got, want, frac = matched(cases.case_decoder, impl, "cpu", 21, dtype=torch.bfloat16, flips="decoder_k21 bf16")
     assert_dicts_close(forward_only(got), forward_only(load_golden("decoder_k21")), BF)
     assert_dicts_close(got, want, BF, BF)
+    assert_grads_l2("decoder_k21 bf16", got, load_golden("decoder_k21"), BF, frac)
 
 
 # ------------------------------------------------- upsample / loss / metrics ----
@@ -168,6 +251,19 @@ def test_ce(impl, name, K):
         assert np.array_equal(np.isnan(got["dlogit"]), np.isnan(want["dlogit"]))
         return
     assert_dicts_close(got, want, 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize("name,K", cases.FOCAL_CFGS)
+def test_focal(impl, name, K):
+    """build_loss('focal') on the HIP cross-entropy against the imported reference's value and gradient."""
+    assert_dicts_close(cases.case_focal(impl, name, K), load_golden("focal_" + name), 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize("K", cases.CW_KS)
+def test_class_balanced_weights(impl, K):
+    """calculate_weigths_labels with the label histogram on the device against the reference's own output."""
+    got = cases.case_class_weights(impl, K)
+    assert np.array_equal(got["weights"], load_golden("class_weights_k%d" % K)["weights"])
 
 
 @pytest.mark.parametrize("K", cases.EVAL_KS)
@@ -192,29 +288,35 @@ def test_evaluator_device_argmax_and_reset(impl):
 
 # ------------------------------------------------------ BASELINE-size head ----
 def test_fullsize_A_fp32(impl):
-    got, want = matched(cases.case_fullsize, impl, "cpu", "A", n=3, backward=True)
+    got, want, frac = matched(cases.case_fullsize, impl, "cpu", "A", n=3, backward=True, flips="fullA")
     assert_dicts_close(forward_only(got), forward_only(load_golden("fullA")), FWD)
     assert_dicts_close(got, want, FWD, GRAD)
-    # unmatched gradients (the reference's own activation pattern): agreement up to the rare sign flips
-    assert_dicts_close(got, load_golden("fullA"), FWD, 1e-1)
+    # unmatched gradients (the reference's own activation pattern)
+    assert_grads_l2("fullA", got, load_golden("fullA"), GRAD, frac)
 
 
 def test_fullsize_A_bf16(impl):
-    got, want = matched(cases.case_fullsize, impl, "cpu", "A", n=3, backward=True, dtype=torch.bfloat16)
+    got, want, frac = matched(cases.case_fullsize, impl, "cpu", "A", n=3, backward=True, dtype=torch.bfloat16,
+                              flips="fullA bf16")
     assert_dicts_close(forward_only(got), forward_only(load_golden("fullA")), BF)
     assert_dicts_close(got, want, BF, BF)
+    assert_grads_l2("fullA bf16", got, load_golden("fullA"), BF, frac)
 
 
-def test_fullsize_D_fp32_forward(impl):
-    got = cases.case_fullsize(impl, "D", n=2, backward=False)
-    assert_dicts_close(got, load_golden("fullD"), FWD, GRAD)
+def test_fullsize_D_fp32(impl):
+    """OS8, 769 x 769: rates 12 / 24 / 36 on a 97 x 97 map, forward, data and weight gradients."""
+    got, want, frac = matched(cases.case_fullsize, impl, "cpu", "D", n=3, backward=True, flips="fullD")
+    assert_dicts_close(forward_only(got), forward_only(load_golden("fullD")), FWD)
+    assert_dicts_close(got, want, FWD, GRAD)
+    assert_grads_l2("fullD", got, load_golden("fullD"), GRAD, frac)
 
 
-def test_fullsize_D_bf16_forward(impl):
-    from segk import config
-    with config.compute_dtype_as(torch.bfloat16):
-        got = cases.case_fullsize(impl, "D", n=2, backward=False)
-    assert_dicts_close(got, load_golden("fullD"), BF, BF)
+def test_fullsize_D_bf16(impl):
+    got, want, frac = matched(cases.case_fullsize, impl, "cpu", "D", n=3, backward=True, dtype=torch.bfloat16,
+                              flips="fullD bf16")
+    assert_dicts_close(forward_only(got), forward_only(load_golden("fullD")), BF)
+    assert_dicts_close(got, want, BF, BF)
+    assert_grads_l2("fullD bf16", got, load_golden("fullD"), BF, frac)
 
 
 # --------------------------------------------------------------- whole model ----
@@ -251,13 +353,25 @@ def test_e2e_first_step_gradients_all_parameters(impl):
 
 
 def _e2e_check(got, want):
-    # The step-1 loss is a pure forward: parity gate.  After one SGD step at lr 0.07 on a random-init net whose
-    # deepest BN layers see 50 values per channel, 1e-6 gradient differences grow to ~1e-3 in the logits
-    # (measured between two CPU runs of the reference graph that differ only in the order of two fp32
-    # additions), so later quantities are compared loosely and the confusion matrix only by its total.
+    # Step 1 is a pure function of the inputs: parity gates.  (The feeder runs on MIOpen here and on oneDNN where
+    # the golden was made, and its deepest batch norms see 25 values per channel, so the logits carry 3e-4 of feeder
+    # difference; a handful of the 14 582 labelled pixels are ties at that level and may be predicted differently.
+    # That the confusion matrix of GIVEN logits is bit-exact is the evaluator tests' business.)
     assert rel_err(got["losses"][:1], want["losses"][:1]) < FWD
+    assert rel_err(got["logits0_sample"], want["logits0_sample"]) < 1e-3
+    assert got["cm0"].sum() == want["cm0"].sum()
+    assert np.abs(got["cm0"] - want["cm0"]).sum() / 2 <= 1e-3 * want["cm0"].sum()
+    for k in want:
+        if k.startswith("w0/"):   # weights and running statistics after the first SGD step
+            assert rel_err(got[k], want[k]) < 1e-4, k
+    # After one SGD step at lr 0.07 on a random-init net, 1e-6 gradient differences grow to ~1e-3 in the weights
+    # and O(1) in individual logits (measured between two CPU runs of the reference graph that differ only in the
+    # order of two fp32 additions), so step-2 quantities are compared loosely, the matrix only by its total.
     assert rel_err(got["losses"][1:], want["losses"][1:]) < 5e-2
     assert got["cm"].sum() == want["cm"].sum()
+    for k in want:
+        if k.startswith("w/"):
+            assert rel_err(got[k], want[k]) < (1e-1 if "running" in k else 1e-2), k
 
 
 def test_e2e_two_sgd_steps_fp32(impl):
@@ -267,6 +381,18 @@ def test_e2e_two_sgd_steps_fp32(impl):
 def test_e2e_hip_syncbn_feeder(impl_sync):
     """sync_bn=True puts the HIP batch norm in all 104 feeder layers as well."""
     _e2e_check(cases.case_e2e(impl_sync), load_golden("e2e"))
+
+
+def test_e2e_hip_optimizer_and_scheduler(impl_sync):
+    """The loop the trainers run (/root/reference/train.py:56-61,143): segk.optim.SGD on the 1x / 10x groups,
+    driven by LR_Scheduler('poly'), against the fixture made with torch.optim.SGD and the reference's scheduler."""
+    import copy
+    from segk.optim import SGD
+    from segk.utils.lr_scheduler import LR_Scheduler
+    hip = copy.copy(impl_sync)
+    hip.optimizer = SGD
+    hip.scheduler = lambda *a: LR_Scheduler(*a, quiet=True)
+    _e2e_check(cases.case_e2e(hip), load_golden("e2e"))
 
 
 # ------------------------------------------------------------ dual attention ----

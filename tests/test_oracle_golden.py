@@ -23,7 +23,8 @@ def oracle_impl():
                       Evaluator=ops_ref.RefEvaluator,
                       DeepLab=lambda: head_ref.RefDeepLab("resnet", 16, 21, nn.BatchNorm2d),
                       lr_groups=lambda m: m.lr_groups(), name="oracle", PAM=damm_ref.RefPAM, CAM=damm_ref.RefCAM,
-                      DAMM=damm_ref.RefDAMM,
+                      DAMM=damm_ref.RefDAMM, focal_loss=lambda lo, t, w: ops_ref.focal_loss(lo, t, w),
+                      class_weights=lambda ds, loader, K: ops_ref.class_weights([b["label"].numpy() for b in loader], K),
                       DeepLabDAMM=lambda: damm_ref.RefDeepLabDAMM("resnet", 16, 8, nn.BatchNorm2d))
 
 
@@ -65,6 +66,19 @@ def test_ce(impl, name, K):
     if name == "all_ignored":
         assert np.isnan(want["loss"]).all() and np.isnan(got["loss"]).all()
     assert_dicts_close(got, want, TOL)
+
+
+@pytest.mark.parametrize("name,K", cases.FOCAL_CFGS)
+def test_focal(impl, name, K):
+    assert_dicts_close(cases.case_focal(impl, name, K), load_golden("focal_" + name), TOL)
+
+
+@pytest.mark.parametrize("K", cases.CW_KS)
+def test_class_weights(impl, K):
+    got = cases.case_class_weights(impl, K)
+    want = load_golden("class_weights_k%d" % K)
+    assert np.array_equal(got["weights"], want["weights"])   # float64 from integer counts: exact
+    assert got["weights"][2] == 1 / np.log(1.02)              # the class that never occurs
 
 
 @pytest.mark.parametrize("K", cases.EVAL_KS)
@@ -121,3 +135,8 @@ def test_e2e_damm(impl):
 @pytest.mark.slow
 def test_fullsize_A(impl):
     assert_dicts_close(cases.case_fullsize(impl, "A", n=3, backward=True), load_golden("fullA"), 1e-4)
+
+
+@pytest.mark.slow
+def test_fullsize_D(impl):
+    assert_dicts_close(cases.case_fullsize(impl, "D", n=3, backward=True), load_golden("fullD"), 1e-4)
