@@ -113,6 +113,85 @@ class SGD(torch.optim.Optimizer):
                      float(hp["weight_decay"]), stream)
         return loss
 
+    # ---- checkpoints (utils/saver.py:33-60 stores optimizer.state_dict(); train.py:124 loads it back) ----------
+    @staticmethod
+    def _shaped(flat, p):
+        """The flat fp32 state of parameter p seen with p's shape and strides."""
+        return torch.as_strided(flat, p.shape, p.stride())
+
+    def state_dict(self):
+        """The layout torch.optim.SGD writes: per parameter a `momentum_buffer` of the parameter's shape (fp32), so
+        either optimizer loads the other's checkpoint.  A bf16-held parameter also stores its fp32 `master` (an
+        entry torch.optim.SGD ignores); an fp32 parameter IS its master and stores none."""
+        packed = super().state_dict()["param_groups"]
+        state = {}
+        idx = 0
+        for g in self.param_groups:
+            for p in g["params"]:
+                st = self.state[p]
+                entry = {"momentum_buffer": self._shaped(st["momentum_buffer"], p).clone()}
+                if p.dtype == torch.bfloat16:
+                    entry["master"] = self._shaped(st["master"], p).clone()
+                state[idx] = entry
+                idx += 1
+        return {"state": state, "param_groups": packed}
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        """Copies the saved values INTO the existing fp32 state tensors (their addresses are in the kernels' tables
+        and, for fp32 parameters, the master is the parameter itself), whatever dtype or device they were saved
+        with.  A parameter without a saved entry gets a zero momentum buffer (= torch's 'no buffer yet').  A
+        bf16-held parameter takes its master from the checkpoint when it has one, otherwise from the parameter's
+        current value (load the weights first; `load_full_precision_state_dict` restores exact masters)."""
+        groups = state_dict["param_groups"]
+        saved = state_dict["state"]
+        if len(groups) != len(self.param_groups):
+            raise ValueError("segk.optim.SGD: checkpoint has %d parameter groups, optimizer has %d"
+                             % (len(groups), len(self.param_groups)))
+        for g, sg in zip(self.param_groups, groups):
+            if len(sg["params"]) != len(g["params"]):
+                raise ValueError("segk.optim.SGD: a parameter group holds %d parameters in the checkpoint, %d here"
+                                 % (len(sg["params"]), len(g["params"])))
+            if sg.get("nesterov") or sg.get("dampening", 0) != 0:
+                raise ValueError("segk.optim.SGD: the checkpoint was written with nesterov / dampening")
+            for key in ("lr", "momentum", "weight_decay"):
+                if key in sg:
+                    g[key] = sg[key]
+            for p, idx in zip(g["params"], sg["params"]):
+                st = self.state[p]
+                entry = saved.get(idx, saved.get(str(idx)))
+                mom = entry.get("momentum_buffer") if entry else None
+                dst = self._shaped(st["momentum_buffer"], p)
+                if mom is None:
+                    dst.zero_()
+                else:
+                    if tuple(mom.shape) != tuple(p.shape):
+                        mom = mom.reshape(p.shape)   # raises on a size mismatch
+                    dst.copy_(mom)
+                if p.dtype == torch.bfloat16:
+                    master = self._shaped(st["master"], p)
+                    if entry and entry.get("master") is not None:
+                        master.copy_(entry["master"].reshape(p.shape))
+                    else:
+                        master.copy_(p.data)
+                    p.data.copy_(master)
+        self._groups = None   # rebuild the chunk tables on the next step
+        self._groups_src = None
+
+    @torch.no_grad()
+    def load_full_precision_state_dict(self, model, state_dict, strict=True):
+        """model.load_state_dict(state_dict) for a model whose weights this optimizer holds in bf16: the fp32 values
+        of the checkpoint go to the masters unrounded, the bf16 copies are re-derived from them."""
+        result = model.load_state_dict(state_dict, strict=strict)
+        by_ptr = {p.data_ptr(): p for g in self.param_groups for p in g["params"] if p.dtype == torch.bfloat16}
+        for k, v in model.state_dict().items():
+            p = by_ptr.get(v.data_ptr()) if torch.is_tensor(v) else None
+            if p is not None and k in state_dict:
+                master = self._shaped(self.state[p]["master"], p)
+                master.copy_(state_dict[k].reshape(p.shape))
+                p.data.copy_(master)
+        return result
+
     def full_precision_state_dict(self, model):
         """model.state_dict() with every bf16-held parameter replaced by its fp32 master."""
         sd = model.state_dict()

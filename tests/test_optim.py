@@ -92,6 +92,91 @@ def test_sgd_bf16_parameters_keep_fp32_master():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("low", [False, True])
+def test_sgd_checkpoint_round_trip_and_interchange_with_torch(low):
+    """step, save, load into FRESH parameters and optimizers, step again (the resume of /root/reference/train.py:
+    112-131): the resumed segk.optim.SGD follows an uninterrupted torch.optim.SGD, its checkpoint loads into
+    torch.optim.SGD and torch's loads into it."""
+    import io
+    from segk.optim import SGD
+    dev = "cuda"
+    init = _grads(SHAPES, 5, dev)
+    gdt = torch.bfloat16 if low else torch.float32
+
+    def fresh(values, cls, **kw):
+        ps = [torch.nn.Parameter(t.clone()) for t in values]
+        if cls is SGD:
+            ps[3].data = ps[3].data.contiguous(memory_format=torch.channels_last)
+            if low:
+                kw["low_precision"] = ps
+        return ps, cls([{"params": ps[:3], "lr": 0.007}, {"params": ps[3:], "lr": 0.07}], momentum=0.9,
+                       weight_decay=5e-4, **kw)
+
+    def run(ps, opt, its):
+        for it in its:
+            for k, (p, g) in enumerate(zip(ps, _grads(SHAPES, 40 + it, dev, gdt))):
+                g = g.to(p.dtype) if p.dtype == torch.bfloat16 else g.float()
+                p.grad = g.contiguous(memory_format=torch.channels_last) if (k == 3 and p.dim() == 4 and
+                                                                             not p.is_contiguous()) else g
+            opt.step()
+
+    def values(ps, opt):
+        if isinstance(opt, SGD) and low:
+            return [opt.state[p]["master"].reshape(-1).clone() if p.is_contiguous() else
+                    SGD._shaped(opt.state[p]["master"], p).contiguous().reshape(-1) for p in ps]
+        return [p.detach().contiguous().reshape(-1).clone() for p in ps]
+
+    ref, oref = fresh(init, torch.optim.SGD)
+    run(ref, oref, range(4))                                     # uninterrupted torch run: 4 steps
+
+    a, oa = fresh(init, SGD)
+    run(a, oa, range(2))
+    buf = io.BytesIO()
+    torch.save({"w": values(a, oa), "optimizer": oa.state_dict()}, buf)
+    buf.seek(0)
+    ck = torch.load(buf, weights_only=True)
+    sd = ck["optimizer"]
+    assert all(v["momentum_buffer"].shape == p.shape and v["momentum_buffer"].dtype == torch.float32
+               for v, p in zip(sd["state"].values(), a))
+    assert all(("master" in v) == low for v in sd["state"].values())
+
+    # (1) resume segk from its own checkpoint, in fresh objects
+    b, ob = fresh([w.reshape(s) for w, s in zip(ck["w"], SHAPES)], SGD)
+    ob.load_state_dict(sd)
+    run(b, ob, range(2, 4))
+    torch.cuda.synchronize()
+    for x, y in zip(values(b, ob), values(ref, oref)):
+        torch.testing.assert_close(x, y, rtol=4e-6, atol=2e-7)
+    if low:
+        for p in b:
+            assert p.dtype == torch.bfloat16
+            assert torch.equal(p.detach(), SGD._shaped(ob.state[p]["master"], p).to(torch.bfloat16))
+
+    # (2) the same checkpoint resumes torch.optim.SGD
+    c, oc = fresh([w.reshape(s) for w, s in zip(ck["w"], SHAPES)], torch.optim.SGD)
+    oc.load_state_dict(sd)
+    run(c, oc, range(2, 4))
+    for x, y in zip(values(c, oc), values(ref, oref)):
+        torch.testing.assert_close(x, y, rtol=4e-6, atol=2e-7)
+
+    # (3) a torch.optim.SGD checkpoint resumes segk, also after segk has already stepped (tables are rebuilt)
+    d, od = fresh(init, torch.optim.SGD)
+    run(d, od, range(2))
+    e, oe = fresh(init, SGD)
+    run(e, oe, range(1))
+    for p, q in zip(e, d):
+        if low:
+            SGD._shaped(oe.state[p]["master"], p).copy_(q.detach())
+        p.data.copy_(q.detach())
+    tsd = od.state_dict()
+    oe.load_state_dict(tsd)
+    run(e, oe, range(2, 4))
+    torch.cuda.synchronize()
+    for x, y in zip(values(e, oe), values(ref, oref)):
+        torch.testing.assert_close(x, y, rtol=(1e-2 if low else 4e-6), atol=(1e-2 if low else 2e-7))
+
+
+@pytest.mark.gpu
 def test_sgd_reads_flat_gradient_buckets():
     """reduce_flat() + step(flat_grads=...) on one rank equals the plain step (mixed fp32 / bf16 parameters, one
     channels_last, one without a gradient)."""
