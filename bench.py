@@ -2,7 +2,7 @@
 """Headline benchmark: train images/sec of DeepLabv3+ (ResNet-101 feeder, OS16, 21 classes, 513x513,
 batch 16 per GPU) with the segmentation head on the HIP kernels.
 
-  python bench.py --gpus N --steps K --warmup W          (N = 1)
+  python bench.py --gpus N --steps K --warmup W          (N > 1: starts N rank processes itself, one per device)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" is what the reference's trainer does per batch (/root/reference/tain_origin.py:124-147): poly-LR
@@ -136,8 +136,40 @@ def measured_traffic(args, families, calls_per_step):
         return None
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this same script (one per device,
+    RCCL through torch.distributed), before this process has made any GPU call, and return their worst exit code.
+    Rank 0's JSON line goes to this process's stdout unchanged."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()   # counts devices without initialising the GPU runtime
+    if have < args.gpus and os.environ.get("SEGK_DIST_BACKEND") != "gloo":   # gloo: rehearsal, ranks share devices
+        print("bench.py: --gpus %d but only %d device(s) visible" % (args.gpus, have), file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = []
+    try:
+        for p in procs:
+            codes.append(p.wait())
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return max(abs(c) for c in codes)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     from segk import config, ops, parallel
     from segk.modeling.deeplab import DeepLab
     from segk.modeling.deeplab_damm import DeepLab as DeepLabDAMM
@@ -145,8 +177,16 @@ def main():
     from segk.utils.lr_scheduler import LR_Scheduler
 
     rank, world = parallel.init_from_env()
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    backend = dist.get_backend() if world > 1 else None
+    if backend == "nccl" and world > torch.cuda.device_count():
+        if rank == 0:
+            print("bench.py: %d ranks but %d device(s) visible (RCCL needs one device per rank)"
+                  % (world, torch.cuda.device_count()), file=sys.stderr)
+        sys.exit(2)
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -253,6 +293,8 @@ def main():
                                       args.dtype,
                                       "HIP SGD, fp32 master weights" if args.optimizer == "hip" else "torch SGD"),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
+                       "world_size": dist.get_world_size() if world > 1 else 1,
+                       "collectives": ("RCCL (torch.distributed nccl backend)" if backend == "nccl" else backend) if world > 1 else None,
                        "final_loss": final_loss},
         }
         if timer is not None:

@@ -77,9 +77,12 @@ class GradientBuckets:
     """
 
     def __init__(self, params, bucket_mb=32.0, overlap=False):
-        """overlap=True: a hook on every parameter starts a bucket's pack + all-reduce the moment its last gradient
-        has been accumulated, so the collectives run under the rest of backward; reduce_flat() then only starts
-        the buckets still missing (parameters without a gradient) and waits."""
+        """overlap=True: a hook on every parameter starts a bucket's pack + all-reduce once its last gradient has been
+        accumulated, so the collectives run under the rest of backward; reduce_flat() then only starts the buckets
+        still missing (parameters without a gradient) and waits.  Collectives are always issued in bucket order
+        (bucket k starts only after buckets 0..k-1), so every rank enqueues the same sequence whatever order its
+        hooks fire in.  A further backward() in the same step (gradient accumulation) marks the buckets it touches;
+        reduce_flat() packs and reduces those again from the accumulated gradients."""
         self.params = [p for p in params if p.requires_grad]
         limit = int(bucket_mb * 1024 * 1024 / 4)
         self.buckets = []
@@ -97,19 +100,27 @@ class GradientBuckets:
         self._works = {}
         self._seen = set()
         self._pending = [len(b) for b in self.buckets]
+        self._ready = set()    # buckets whose gradients are complete but whose turn has not come
+        self._next = 0         # first bucket not started yet (hook path)
+        self._dirty = set()    # buckets that received gradients again after their all-reduce was started
         self._bucket_of = {id(p): k for k, b in enumerate(self.buckets) for p in b}
         if overlap:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
     def _on_grad(self, p):
-        if id(p) in self._seen:   # a second backward in the same step: the bucket is packed again at reduce_flat()
+        k = self._bucket_of[id(p)]
+        if id(p) in self._seen:   # a further backward in the same step: p.grad has grown since the bucket was packed
+            if k in self._works:
+                self._dirty.add(k)
             return
         self._seen.add(id(p))
-        k = self._bucket_of[id(p)]
         self._pending[k] -= 1
         if self._pending[k] == 0:
-            self._start(k)
+            self._ready.add(k)
+            while self._next in self._ready:
+                self._start(self._next)
+                self._next += 1
 
     def view_of(self, p):
         """The slice of a flat bucket that holds parameter p's (summed) gradient after reduce_flat()."""
@@ -176,12 +187,19 @@ class GradientBuckets:
         for k in range(len(self.buckets)):
             if k not in self._works:
                 self._start(k)
+        for k in sorted(self._dirty):   # packed before the last backward of this step: wait, pack and reduce again
+            if self._works[k] is not None:
+                self._works[k].wait()
+            self._start(k)
         for w in self._works.values():
             if w is not None:
                 w.wait()
         self._works = {}
         self._seen = set()
         self._pending = [len(b) for b in self.buckets]
+        self._ready = set()
+        self._next = 0
+        self._dirty = set()
         return self
 
     def _buffers(self):

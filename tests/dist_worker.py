@@ -4,6 +4,7 @@ MODE cpu : gloo on CPU tensors - the three exchanges of segk.parallel (BN statis
            gradient buckets) with the local arithmetic done by the oracle; each rank owns a shard of the batch.
 MODE gpu : gloo on CUDA tensors, every rank on cuda:0 (one-GPU box) - the real HIP modules with
            SynchronizedBatchNorm2d in feeder and head, head-only model to keep it quick.
+MODE nccl: the same with rank r on cuda:r over RCCL (needs WORLD devices).
 Each rank writes OUTDIR/rank{R}.npz; the parent compares with a single process that ran the whole batch.
 """
 import os
@@ -95,7 +96,7 @@ def run_cpu(rank, world, outdir):
 GPU_N, GPU_K = 4, 7
 
 
-def gpu_case(device, images, sync, overlap_buckets=None):
+def gpu_case(device, images, sync, overlap_buckets=None, backwards=1):
     """Head + a small SyncBN'd stem standing in for the feeder, one SGD-free step; returns loss, grads.
     overlap_buckets (MB): attach GradientBuckets(overlap=True) before backward and finish them (net.overlapped)."""
     from segk.modeling.aspp import build_aspp
@@ -135,18 +136,21 @@ def gpu_case(device, images, sync, overlap_buckets=None):
         net.overlapped = parallel.GradientBuckets(list(net.parameters()), bucket_mb=overlap_buckets, overlap=True)
     out = net(img)
     loss = SegmentationLosses(cuda=True).build_loss("ce")(out, tgt)
-    loss.backward()
+    for i in range(backwards):   # gradient accumulation: the parts add up to the gradient of the loss
+        (loss / backwards).backward(retain_graph=i + 1 < backwards)
     if overlap_buckets is not None:
         net.overlapped.reduce_flat()
     return net, loss, out
 
 
-def run_gpu(rank, world, outdir):
+def run_gpu(rank, world, outdir, device="cuda:0"):
     from segk import parallel
     per = GPU_N // world
-    net, loss, out = gpu_case("cuda:0", (rank * per, (rank + 1) * per), True)
+    net, loss, out = gpu_case(device, (rank * per, (rank + 1) * per), True)
     # a second pass with hooks that start each bucket during backward: its sums must equal the ones started after
-    net2, loss2, _ = gpu_case("cuda:0", (rank * per, (rank + 1) * per), True, overlap_buckets=0.5)
+    net2, loss2, _ = gpu_case(device, (rank * per, (rank + 1) * per), True, overlap_buckets=0.5)
+    # and a third whose loss is back-propagated in two halves: buckets started during the first half are reduced again
+    net3, _, _ = gpu_case(device, (rank * per, (rank + 1) * per), True, overlap_buckets=0.5, backwards=2)
     buckets = parallel.GradientBuckets(list(net.parameters()), bucket_mb=0.5)
     # the flat form first (it leaves p.grad alone), then the copy-back form: both must hold the same sums
     buckets.reduce_flat()
@@ -158,6 +162,8 @@ def run_gpu(rank, world, outdir):
         res["f/" + n] = flat[n]
     for n, p in net2.named_parameters():
         res["o/" + n] = net2.overlapped.view_of(p).detach().reshape(p.shape).cpu().numpy()
+    for n, p in net3.named_parameters():
+        res["a/" + n] = net3.overlapped.view_of(p).detach().reshape(p.shape).cpu().numpy()
     for n, b in net.named_buffers():
         if b.is_floating_point():
             res["b/" + n] = b.detach().cpu().numpy()
@@ -169,11 +175,16 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import faulthandler
     faulthandler.dump_traceback_later(60, exit=True)  # a stuck collective names its call site instead of hanging the test
+    if mode == "nccl":   # one rank per device over RCCL, the production transport
+        torch.cuda.set_device(rank)
     if world > 1:
-        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % port, rank=rank, world_size=world)
+        dist.init_process_group("nccl" if mode == "nccl" else "gloo", init_method="tcp://127.0.0.1:%s" % port,
+                                rank=rank, world_size=world)
     torch.set_num_threads(2)
     if mode == "cpu":
         run_cpu(rank, world, outdir)
+    elif mode == "nccl":
+        run_gpu(rank, world, outdir, device="cuda:%d" % rank)
     else:
         torch.cuda.set_device(0)
         run_gpu(rank, world, outdir)

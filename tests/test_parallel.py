@@ -74,13 +74,8 @@ def test_two_ranks_equal_one_rank_cpu_protocol():
     assert rel_err(cat("dlogits"), lr.grad.numpy()) < 1e-5
 
 
-@pytest.mark.gpu
-def test_two_ranks_equal_one_rank_hip_modules():
-    import dist_worker as dw
-    assert torch.cuda.is_available()
-    with tempfile.TemporaryDirectory() as d:
-        ranks = launch("gpu", 2, d)
-        single = launch("gpu", 1, d)[0]
+def _check_ranks_against_single(ranks, single, grad_l2):
+    from helpers import rel_l2
     out = np.concatenate([r["out"] for r in ranks])
     assert rel_err(out, single["out"]) < 1e-4
     for r in ranks:
@@ -88,17 +83,45 @@ def test_two_ranks_equal_one_rank_hip_modules():
         for k, v in single.items():
             if k.startswith("b/"):
                 assert rel_err(r[k], v) < 1e-4, k
-    # gradients: ranks agree exactly with each other (same all-reduced buckets) and with the single process
-    # up to ReLU sign flips of near-zero activations (see test_gpu_modules): L2-relative
-    from helpers import rel_l2
+    # gradients: ranks agree exactly with each other (same all-reduced buckets) and with the single process up to
+    # summation order (and the rare ReLU sign flip of a near-zero activation, see test_gpu_modules): L2-relative
+    worst = 0.0
     for k, v in single.items():
         if k.startswith("d/"):
-            assert np.array_equal(ranks[0][k], ranks[1][k]), k
-            assert rel_l2(ranks[0][k], v) < 2e-2, (k, rel_l2(ranks[0][k], v))
+            for r in ranks[1:]:
+                assert np.array_equal(ranks[0][k], r[k]), k
+            worst = max(worst, rel_l2(ranks[0][k], v))
+            assert rel_l2(ranks[0][k], v) < grad_l2, (k, rel_l2(ranks[0][k], v))
             # the flat buckets the device optimizer reads hold the same sums as the copied-back gradients
             f = "f/" + k[2:]
-            assert np.array_equal(ranks[0][f], ranks[0][k]) and np.array_equal(ranks[1][f], ranks[0][k]), f
+            assert all(np.array_equal(r[f], ranks[0][k]) for r in ranks), f
             # ... also when hooks start each bucket's all-reduce during backward (a second, identical pass)
             o = "o/" + k[2:]
-            assert np.array_equal(ranks[0][o], ranks[1][o]), o
+            assert all(np.array_equal(ranks[0][o], r[o]) for r in ranks[1:]), o
             assert rel_l2(ranks[0][o], ranks[0][k]) < 1e-5, (o, rel_l2(ranks[0][o], ranks[0][k]))
+            # ... and when the loss is back-propagated in two halves (buckets packed early are reduced again)
+            a = "a/" + k[2:]
+            assert all(np.array_equal(ranks[0][a], r[a]) for r in ranks[1:]), a
+            assert rel_l2(ranks[0][a], ranks[0][k]) < 1e-5, (a, rel_l2(ranks[0][a], ranks[0][k]))
+    print("worst gradient rel_l2, %d ranks against one: %.3e" % (len(ranks), worst))
+
+
+@pytest.mark.gpu
+def test_two_ranks_equal_one_rank_hip_modules():
+    assert torch.cuda.is_available()
+    with tempfile.TemporaryDirectory() as d:
+        ranks = launch("gpu", 2, d)
+        single = launch("gpu", 1, d)[0]
+    _check_ranks_against_single(ranks, single, 1e-3)
+
+
+@pytest.mark.gpu
+def test_ranks_on_separate_devices_rccl():
+    """One rank per device over RCCL (torch.distributed backend "nccl"): 2 devices x half the batch equal one
+    device x the whole batch (/root/reference/train.py:105-110 with --gpu-ids 0,1)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the round-end box has one); the same worker runs over gloo above")
+    with tempfile.TemporaryDirectory() as d:
+        ranks = launch("nccl", 2, d)
+        single = launch("gpu", 1, d)[0]
+    _check_ranks_against_single(ranks, single, 1e-3)
