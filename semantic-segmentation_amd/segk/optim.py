@@ -75,7 +75,10 @@ class SGD(torch.optim.Optimizer):
                  low_precision=()):
         if nesterov or dampening != 0.0:
             raise ValueError("segk.optim.SGD: nesterov / dampening are not implemented (the reference uses neither)")
-        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        # the group keys torch.optim.SGD writes, so that its load_state_dict accepts a checkpoint from here
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=0.0, weight_decay=weight_decay,
+                                      nesterov=False, maximize=False, foreach=None, differentiable=False,
+                                      fused=None))
         _lib.load()
         low = {id(p) for p in low_precision}
         self._groups = None
@@ -152,8 +155,8 @@ class SGD(torch.optim.Optimizer):
             if len(sg["params"]) != len(g["params"]):
                 raise ValueError("segk.optim.SGD: a parameter group holds %d parameters in the checkpoint, %d here"
                                  % (len(sg["params"]), len(g["params"])))
-            if sg.get("nesterov") or sg.get("dampening", 0) != 0:
-                raise ValueError("segk.optim.SGD: the checkpoint was written with nesterov / dampening")
+            if sg.get("nesterov") or sg.get("dampening", 0) != 0 or sg.get("maximize"):
+                raise ValueError("segk.optim.SGD: the checkpoint was written with nesterov / dampening / maximize")
             for key in ("lr", "momentum", "weight_decay"):
                 if key in sg:
                     g[key] = sg[key]
