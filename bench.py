@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--feeder-fp32", action="store_true", help="run the PyTorch feeder in fp32 even in bf16 mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 leg of the default workload")
+    ap.add_argument("--fp32-steps", type=int, default=4)
+    ap.add_argument("--no-torch-baseline", action="store_true",
+                    help="skip timing the oracle modules on PyTorch-ROCm (the reference path on this GPU)")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-miopen-benchmark", action="store_true",
@@ -72,6 +76,27 @@ def parse():
     return args
 
 
+_T0 = time.perf_counter()
+
+
+def progress(msg):
+    """Phase marker on stderr (the JSON line on stdout stays the only stdout output)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %6.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+def heartbeat(period=60.0):
+    """A line on stderr every minute from a daemon thread, so that a long MIOpen algorithm search in the first step
+    does not look like a hang to whoever watches the run."""
+    import threading
+
+    def beat():
+        while True:
+            time.sleep(period)
+            progress("... still running")
+    threading.Thread(target=beat, daemon=True).start()
+
+
 def synthetic_batch(batch, size, classes, device, seed):
     g = torch.Generator(device="cpu").manual_seed(seed)
     image = torch.randn((batch, 3, size, size), generator=g)
@@ -83,7 +108,8 @@ def synthetic_batch(batch, size, classes, device, seed):
 
 
 def cpu_baseline(args):
-    """The oracle's restatement of the same training step (+ Evaluator) on the host cores."""
+    """The oracle's restatement of the same training step on the host cores: exactly the work the GPU `value`
+    times (scheduler, zero_grad, forward, loss, backward, SGD); the Evaluator is timed on its own beside it."""
     import torch.nn as nn
     from oracle import head_ref, ops_ref
     torch.manual_seed(1)
@@ -94,26 +120,83 @@ def cpu_baseline(args):
     opt = torch.optim.SGD([{"params": g1, "lr": 0.007}, {"params": g10, "lr": 0.07}], momentum=0.9, weight_decay=5e-4)
     image, target = synthetic_batch(args.cpu_batch, args.size, args.classes, "cpu", 1)
     ev = ops_ref.RefEvaluator(args.classes)
+    keep = {}
 
-    def step():
+    def step(i):
+        lr = ops_ref.poly_lr(0.007, i, 50000)
+        opt.param_groups[0]["lr"], opt.param_groups[1]["lr"] = lr, 10 * lr
         opt.zero_grad()
         out = model(image)
         loss = ops_ref.ce_loss(out, target)
         loss.backward()
         opt.step()
-        ev.add_batch(target.numpy(), ops_ref.predict(out.detach().numpy()))
+        keep["out"] = out.detach()
 
-    step()
+    progress("CPU baseline: warm-up step")
+    step(0)
     times = []
-    for _ in range(2):
+    for i in range(2):
         t0 = time.perf_counter()
-        step()
+        step(1 + i)
         times.append(time.perf_counter() - t0)
+        progress("CPU baseline: timed step %d: %.2f s" % (i, times[-1]))
     sec = float(np.median(times))
+    t0 = time.perf_counter()
+    ev.add_batch(target.numpy(), ops_ref.predict(keep["out"].numpy()))   # train.py:215-219 on the host
+    ev_sec = time.perf_counter() - t0
     return {"value": args.cpu_batch / sec, "unit": "images/sec", "cores": threads, "kind": "port",
             "sample": "oracle (plain PyTorch fp32) DeepLabv3+ R101 OS%d K=%d batch %d %dx%d: 1 warm-up + 2 timed "
-                      "train steps incl. host argmax + confusion matrix, median %.2f s/step"
-                      % (args.out_stride, args.classes, args.cpu_batch, args.size, args.size, sec)}
+                      "train steps (the work `value` times), median %.2f s/step"
+                      % (args.out_stride, args.classes, args.cpu_batch, args.size, args.size, sec),
+            "evaluator_images_per_sec": args.cpu_batch / ev_sec,
+            "evaluator_sample": "host argmax + confusion matrix of one batch of %d: %.3f s" % (args.cpu_batch, ev_sec)}
+
+
+def torch_rocm_baseline(args, dev):
+    """The oracle modules (the reference's graph in plain PyTorch) on this GPU through PyTorch-ROCm / MIOpen: the
+    'reference path on ROCm' the HIP path replaces.  fp32 as the reference runs it, and bf16 autocast with
+    channels_last tensors, the fastest stock configuration."""
+    import torch.nn as nn
+    from oracle import head_ref, ops_ref
+    out = {}
+    image, target = synthetic_batch(args.batch, args.size, args.classes, dev, 1)
+    for tag, amp in (("fp32", False), ("bf16_autocast_channels_last", True)):
+        torch.manual_seed(1)
+        model = head_ref.RefDeepLab("resnet", args.out_stride, args.classes, nn.BatchNorm2d).to(dev)
+        if amp:
+            model = model.to(memory_format=torch.channels_last)
+        model.train()
+        g1, g10 = model.lr_groups()
+        opt = torch.optim.SGD([{"params": g1, "lr": 0.007}, {"params": g10, "lr": 0.07}], momentum=0.9, weight_decay=5e-4)
+        img = image.contiguous(memory_format=torch.channels_last) if amp else image
+
+        def step(i):
+            lr = ops_ref.poly_lr(0.007, i, 50000)
+            opt.param_groups[0]["lr"], opt.param_groups[1]["lr"] = lr, 10 * lr
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=amp):
+                logits = model(img)
+            loss = ops_ref.ce_loss(logits.float(), target)
+            loss.backward()
+            opt.step()
+
+        progress("PyTorch-ROCm baseline %s: warm-up" % tag)
+        for i in range(3):
+            step(i)
+            torch.cuda.synchronize()
+            progress("PyTorch-ROCm baseline %s: warm-up step %d done" % (tag, i))
+        t0 = time.perf_counter()
+        n = 5
+        for i in range(n):
+            step(3 + i)
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - t0) / n
+        out[tag] = {"value": args.batch / sec, "unit": "images/sec", "ms_per_step": 1000.0 * sec}
+        del model, opt
+        torch.cuda.empty_cache()
+    out["sample"] = ("oracle.head_ref.RefDeepLab + torch.optim.SGD on PyTorch-ROCm (MIOpen, algorithm search %s), batch %d, "
+                     "3 warm-up + 5 timed steps" % ("on" if torch.backends.cudnn.benchmark else "off", args.batch))
+    return out
 
 
 def measured_traffic(args, families, calls_per_step):
@@ -190,91 +273,153 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    cd = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    config.set_compute_dtype(cd)
-    feeder_amp = args.dtype == "bf16" and not args.feeder_fp32
-
-    torch.backends.cudnn.benchmark = not args.no_miopen_benchmark
-    torch.manual_seed(1)  # the reference's --seed default; identical initial weights on every rank
+    search = not args.no_miopen_benchmark
+    if rank == 0:
+        heartbeat()
     sync_bn = (world > 1) if args.sync_bn == "auto" else (args.sync_bn == "on")
-    ctor = DeepLabDAMM if args.config == "E" else DeepLab
-    model = ctor(backbone="resnet", output_stride=args.out_stride, num_classes=args.classes, sync_bn=sync_bn).to(dev)
-    if args.config == "E":
-        # the reference initialises both attention gammas to 0 (identity branch); give them the value a trained
-        # model would have so the attention products are not multiplied by zero
-        for m in (model.damm.damm1, model.damm.damm2):
-            m.gamma.data.fill_(0.5)
-    model.train()
-    if feeder_amp:
-        fmt = torch.contiguous_format if args.feeder_nchw else torch.channels_last
-        model.backbone = model.backbone.to(memory_format=fmt)
-        feeder_fwd = model.backbone.forward
 
-        def amp_forward(x):
-            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
-                return feeder_fwd(x.contiguous(memory_format=fmt))
-        model.backbone.forward = amp_forward
-    groups = [{"params": list(model.get_1x_lr_params()), "lr": 0.007},
-              {"params": list(model.get_10x_lr_params()), "lr": 0.07}]
-    if args.optimizer == "hip":
-        from segk.optim import SGD
-        low = [m.weight for m in model.backbone.modules() if isinstance(m, torch.nn.Conv2d)] if feeder_amp else []
-        opt = SGD(groups, momentum=0.9, weight_decay=5e-4, nesterov=False, low_precision=low)
-    else:
-        opt = torch.optim.SGD(groups, momentum=0.9, weight_decay=5e-4, nesterov=False)
-    criterion = SegmentationLosses(weight=None, cuda=True).build_loss("ce")
-    scheduler = LR_Scheduler("poly", 0.007, 50, 1000, quiet=True)
-    buckets = parallel.GradientBuckets([p for g in opt.param_groups for p in g["params"]],
-                                       overlap=world > 1 and args.optimizer == "hip")
-    image, target = synthetic_batch(args.batch, args.size, args.classes, dev, 1 + rank)
+    def measure(dtype, steps, warmup, detailed):
+        """Build the model in `dtype`, run warmup + steps training steps, return the timings.  detailed: HIP events
+        around the convolution calls inside the timed steps (about 1 % of the step), one extra untimed step with
+        events around the memory-bound launches as well, and an untimed evaluation leg."""
+        cd = torch.bfloat16 if dtype == "bf16" else torch.float32
+        config.set_compute_dtype(cd)
+        # MIOpen's timed algorithm search (about 100 s of the first bf16 step) only for the headline leg: the fp32
+        # search runs for minutes
+        torch.backends.cudnn.benchmark = search and dtype == args.dtype
+        feeder_amp = dtype == "bf16" and not args.feeder_fp32
+        torch.manual_seed(1)  # the reference's --seed default; identical initial weights on every rank
+        ctor = DeepLabDAMM if args.config == "E" else DeepLab
+        model = ctor(backbone="resnet", output_stride=args.out_stride, num_classes=args.classes, sync_bn=sync_bn).to(dev)
+        if args.config == "E":
+            # the reference initialises both attention gammas to 0 (identity branch); give them the value a trained
+            # model would have so the attention products are not multiplied by zero
+            for m in (model.damm.damm1, model.damm.damm2):
+                m.gamma.data.fill_(0.5)
+        model.train()
+        if feeder_amp:
+            fmt = torch.contiguous_format if args.feeder_nchw else torch.channels_last
+            model.backbone = model.backbone.to(memory_format=fmt)
+            feeder_fwd = model.backbone.forward
 
-    def step(i):
-        scheduler(opt, i, 0, 0.0)
-        opt.zero_grad(set_to_none=True)
-        if args.fused_loss:
-            loss = model.forward_loss(image, target)
+            def amp_forward(x):
+                with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                    return feeder_fwd(x.contiguous(memory_format=fmt))
+            model.backbone.forward = amp_forward
+        groups = [{"params": list(model.get_1x_lr_params()), "lr": 0.007},
+                  {"params": list(model.get_10x_lr_params()), "lr": 0.07}]
+        if args.optimizer == "hip":
+            from segk.optim import SGD
+            low = [m.weight for m in model.backbone.modules() if isinstance(m, torch.nn.Conv2d)] if feeder_amp else []
+            opt = SGD(groups, momentum=0.9, weight_decay=5e-4, nesterov=False, low_precision=low)
         else:
-            out = model(image)
-            loss = criterion(out, target)
-        loss.backward()
-        if world > 1 and args.optimizer == "hip":
-            opt.step(flat_grads=buckets.reduce_flat())   # the optimizer reads the all-reduced buckets in place
-        else:
-            buckets.reduce()
-            opt.step()
-        return loss
+            opt = torch.optim.SGD(groups, momentum=0.9, weight_decay=5e-4, nesterov=False)
+        criterion = SegmentationLosses(weight=None, cuda=True).build_loss("ce")
+        scheduler = LR_Scheduler("poly", 0.007, 50, 1000, quiet=True)
+        buckets = parallel.GradientBuckets([p for g in opt.param_groups for p in g["params"]],
+                                           overlap=world > 1 and args.optimizer == "hip")
+        image, target = synthetic_batch(args.batch, args.size, args.classes, dev, 1 + rank)
 
-    for i in range(args.warmup):
-        step(i)
-    timer = None
-    if not args.no_kernel_timing:
-        timer = ops.KernelTimer()
-        ops.TIMER = timer
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    conv_summ = timer.summary() if timer is not None else None   # the convolution figures: timed steps only
-    if timer is not None:
-        # one extra, untimed step with events around the ~420 memory-bound batch-norm launches as well (their
-        # 840 events would cost the timed region about 1.5 %)
-        timer.hbm = True
-        step(args.warmup + args.steps)
+        def step(i):
+            scheduler(opt, i, 0, 0.0)
+            opt.zero_grad(set_to_none=True)
+            if args.fused_loss:
+                loss = model.forward_loss(image, target)
+            else:
+                out = model(image)
+                loss = criterion(out, target)
+            loss.backward()
+            if world > 1 and args.optimizer == "hip":
+                opt.step(flat_grads=buckets.reduce_flat())   # the optimizer reads the all-reduced buckets in place
+            else:
+                buckets.reduce()
+                opt.step()
+            return loss
+
+        progress("%s: model built, %d warm-up steps" % (dtype, warmup))
+        for i in range(warmup):
+            step(i)
+            if i == 0:
+                torch.cuda.synchronize()
+                progress("%s: first step done (MIOpen algorithm search included)" % dtype)
+        timer = None
+        if detailed:
+            timer = ops.KernelTimer()
+            ops.TIMER = timer
         torch.cuda.synchronize()
-    ops.TIMER = None
-    final_loss = float(loss.detach())
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = step(warmup + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        progress("%s: %d timed steps, %.2f ms/step" % (dtype, steps, 1000.0 * elapsed / steps))
+        res = {"final_loss": float(loss.detach()), "feeder_amp": feeder_amp, "conv": None, "hbm": None}
+        if timer is not None:
+            torch.cuda.synchronize()
+            res["conv"] = timer.summary()   # the convolution figures: timed steps only
+            # one extra, untimed step with events around the ~450 memory-bound launches as well (their events
+            # would cost the timed region about 1.5 %), then an untimed evaluation leg (train.py:215-219 on the
+            # device): class argmax + confusion matrix of the step's logits, and the fused upsample + argmax form
+            timer.records = {}
+            timer.hbm = True
+            step(warmup + steps)
+            torch.cuda.synchronize()
+            res["hbm"] = timer.summary()
+            timer.records = {}
+            from segk.utils.metrics import Evaluator
+            with torch.no_grad():
+                x, low = model.backbone(image)
+                low_logits = model.decoder(model.aspp(x), low)
+                import segk.functional as SF
+                logits = SF.interpolate_bilinear_ac(low_logits, image.shape[2:])
+                ev = Evaluator(args.classes)
+                ev.add_logits(target, logits)
+                ev.add_low_logits(target, low_logits)
+            torch.cuda.synchronize()
+            res["eval"] = timer.summary()
+        ops.TIMER = None
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t)
+        res["elapsed"] = elapsed
+        del model, opt, buckets
+        torch.cuda.empty_cache()
+        return res
+
+    def conv_rooflines(res, dtype, steps, elapsed):
+        """roofline objects of the two MFMA kernel families from the HIP-event records of the timed steps."""
+        out = {}
+        peak = BF16_DENSE_PEAK_TFLOPS if dtype == "bf16" else FP32_MATRIX_PEAK_TFLOPS
+        dom = res["conv"].get("conv_fwd_kernel")
+        if dom:
+            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                               "traffic": None,
+                               "kernel": "conv_fwd_dma_kernel / conv_fwd_kernel (implicit-GEMM forward + data "
+                               "gradient, all %d segk_conv_fwd calls of the timed steps, each bracketed by two HIP events on "
+                               "the launch stream; a call is one launch or a main + tail pair)" % dom["launches"],
+                               "avg_launch_ms": dom["avg_ms"], "share_of_step": dom["ms"] / (1000.0 * elapsed)}
+        wg = res["conv"].get("conv_wgrad_kernel")
+        if wg:
+            ach = wg["flops"] / (wg["ms"] * 1e-3) / 1e12
+            out["roofline_wgrad"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                                     "avg_launch_ms": wg["avg_ms"],
+                                     "kernel": "conv_wgrad_kernel / conv_wgrad_dma_kernel + wgrad_finish_kernel (%d "
+                                               "weight gradients: the split-slab launch and the fixed-order slab sum "
+                                               "inside one bracket)" % wg["launches"],
+                                     "share_of_step": wg["ms"] / (1000.0 * elapsed)}
+        return out
+
+    main_res = measure(args.dtype, args.steps, args.warmup, not args.no_kernel_timing)
+    elapsed = main_res["elapsed"]
+    feeder_amp = main_res["feeder_amp"]
 
     if rank == 0:
         images = world * args.batch * args.steps
@@ -295,33 +440,18 @@ def main():
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "collectives": ("RCCL (torch.distributed nccl backend)" if backend == "nccl" else backend) if world > 1 else None,
-                       "final_loss": final_loss},
+                       "final_loss": main_res["final_loss"]},
         }
-        if timer is not None:
-            summ = timer.summary()
-            dom = conv_summ.get("conv_fwd_kernel")
-            if dom:
-                peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MATRIX_PEAK_TFLOPS
-                ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-                line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                                    "frac": ach / peak,
-                                    "traffic": measured_traffic(args, ("conv_fwd_dma_kernel", "conv_fwd_kernel"),
-                                                                dom["launches"] / float(args.steps)),
-                                    "traffic_unit": "HBM bytes per segk_conv_fwd call (rocprofv3 FETCH_SIZE x2 + "
-                                                    "WRITE_SIZE, profiles/pmc_traffic.json)",
-                                    "kernel": "conv_fwd_dma_kernel / conv_fwd_kernel (implicit-GEMM forward + data "
-                                    "gradient, all %d segk_conv_fwd calls of the timed steps; a call is one launch or "
-                                    "a main + tail pair)" % dom["launches"],
-                                    "avg_launch_ms": dom["avg_ms"],
-                                    "share_of_step": dom["ms"] / (1000.0 * elapsed)}
-            wg = conv_summ.get("conv_wgrad_kernel")
-            if wg:
-                peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MATRIX_PEAK_TFLOPS
-                ach = wg["flops"] / (wg["ms"] * 1e-3) / 1e12
-                line["roofline_wgrad"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                                          "frac": ach / peak, "avg_launch_ms": wg["avg_ms"],
-                                          "kernel": "conv_wgrad_kernel / conv_wgrad_dma_kernel (%d calls)" % wg["launches"],
-                                          "share_of_step": wg["ms"] / (1000.0 * elapsed)}
+        if main_res["conv"] is not None:
+            line.update(conv_rooflines(main_res, args.dtype, args.steps, elapsed))
+            if "roofline" in line:
+                calls = main_res["conv"]["conv_fwd_kernel"]["launches"] / float(args.steps)
+                line["roofline"]["traffic"] = measured_traffic(args, ("conv_fwd_dma_kernel", "conv_fwd_kernel",
+                                                                      "conv_fwd_halo_kernel"), calls)
+                line["roofline"]["traffic_unit"] = ("HBM bytes per segk_conv_fwd call (rocprofv3 FETCH_SIZE x2 + "
+                                                    "WRITE_SIZE, profiles/pmc_traffic.json)")
+            summ = main_res["hbm"]
+            step_ms = 1000.0 * elapsed / args.steps
             bn = [v for k, v in summ.items() if k.startswith("bn_")]
             if bn:
                 nbytes, ms = sum(v["flops"] for v in bn), sum(v["ms"] for v in bn)
@@ -331,9 +461,39 @@ def main():
                                         "kernel": "bn_stats / bn_apply / bn_bwd_stats / bn_bwd_apply (pixel-major batch "
                                                   "norm, %d launches of one extra step after the timed region; algorithmic bytes = every "
                                                   "operand tensor once)" % sum(v["launches"] for v in bn),
-                                        "share_of_step": ms / (1000.0 * elapsed / args.steps)}
-        if world == 1 and not args.no_cpu_baseline and args.config == "A":
-            del model, opt, buckets
+                                        "share_of_step": ms / step_ms}
+            # the other memory-bound kernels of the path, each against the same 8 TB/s: algorithmic bytes of the
+            # kernel's real operand types / HIP-event time, from the extra step and the evaluation leg
+            others = {}
+            for name in ("upsample_fwd", "upsample_bwd", "ce_fwd", "ce_bwd", "upsample_ce_fwd", "upsample_ce_bwd",
+                         "argmax", "confmat", "upsample_argmax", "pack_weight"):
+                in_step = name not in ("argmax", "confmat", "upsample_argmax")
+                v = (summ if in_step else main_res["eval"]).get(name)
+                if v and v["ms"] > 0:
+                    ach = v["flops"] / (v["ms"] * 1e-3) / 1e9
+                    others[name] = {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "launches": v["launches"],
+                                    "avg_launch_ms": v["avg_ms"], "bytes_per_launch": v["flops"] / v["launches"],
+                                    "in_step": in_step}
+            if others:
+                line["roofline_hbm_kernels"] = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernels": others,
+                                                "note": "argmax / confmat / upsample_argmax: evaluation leg after the "
+                                                        "timed region (Evaluator.add_logits, add_low_logits), not part of `value`"}
+        default_workload = world == 1 and args.config == "A"
+        if default_workload and not args.no_fp32 and args.dtype == "bf16":
+            # the fp32 half of the same configuration (exact-fp32 MFMA in the head, fp32 feeder), a short loop
+            torch.backends.cudnn.benchmark = False
+            r32 = measure("fp32", args.fp32_steps, 2, not args.no_kernel_timing)
+            e32 = r32["elapsed"]
+            line["fp32"] = {"value": args.batch * args.fp32_steps / e32, "unit": "images/sec", "steps": args.fp32_steps,
+                            "warmup": 2, "ms_per_step": 1000.0 * e32 / args.fp32_steps, "final_loss": r32["final_loss"],
+                            "workload": "the same step with fp32 operands everywhere (exact-fp32 MFMA in the head, "
+                                        "fp32 feeder convolutions with MIOpen's default algorithm choice, no timed search)"}
+            if r32["conv"] is not None:
+                line["fp32"].update(conv_rooflines(r32, "fp32", args.fp32_steps, e32))
+        if default_workload and not args.no_torch_baseline:
+            torch.backends.cudnn.benchmark = False
+            line["torch_rocm_baseline"] = torch_rocm_baseline(args, dev)
+        if default_workload and not args.no_cpu_baseline:
             torch.cuda.empty_cache()
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line), flush=True)

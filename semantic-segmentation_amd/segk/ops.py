@@ -142,7 +142,9 @@ def pack_weight(w, dtype, transpose=False, out=None):
         out = torch.empty(shape, dtype=dtype, device=w.device)
     elif tuple(out.shape) != shape or out.dtype != dtype or not out.is_contiguous():
         raise ValueError("pack_weight destination must be a contiguous %s tensor of shape %s" % (dtype, shape))
+    t0 = _hbm_start()
     call("segk_pack_weight", _ptr(w), _ptr(out), _dt(out), Cout, Cin, R, 1 if transpose else 0, _stream())
+    _hbm_stop("pack_weight", _nbytes(w, out), t0)
     return out
 
 
@@ -241,12 +243,13 @@ def conv_wgrad(x, dout, N, H, W, R, dil, Cout_true, Cin_true, splits=None):
     a.inp, a.in_ld, a.Cin = x.data_ptr(), in_ld, Cin
     a.dout, a.dout_ld, a.Cout = dout.data_ptr(), do_ld, Cout
     a.R, a.dil, a.splits, a.slabs = R, dil, splits, slabs.data_ptr()
+    dw = torch.empty((Cout_true, Cin_true, R, R), dtype=torch.float32, device=x.device)
+    # the bracket holds the split-slab kernel AND the fixed-order sum of the slabs: the whole weight-gradient cost
     t0 = TIMER.start() if TIMER is not None else None
     call("segk_conv_wgrad", ctypes.byref(a), _stream())
+    call("segk_wgrad_finish", _ptr(slabs), splits, R, Cin, Cout, _ptr(dw), Cout_true, Cin_true, _stream())
     if t0 is not None:
         TIMER.stop("conv_wgrad_kernel", 2.0 * M * Cout_true * Cin_true * R * R, t0)
-    dw = torch.empty((Cout_true, Cin_true, R, R), dtype=torch.float32, device=x.device)
-    call("segk_wgrad_finish", _ptr(slabs), splits, R, Cin, Cout, _ptr(dw), Cout_true, Cin_true, _stream())
     return dw
 
 
@@ -594,8 +597,11 @@ def upsample_fwd(src, N, C, Hi, Wi, dst, Ho, Wo, dst_layout=PM):
         out_ld = 0
         if tuple(dst.shape) != (N, C, Ho, Wo) or not dst.is_contiguous():
             raise ValueError("NCHW destination must be contiguous [N,C,Ho,Wo]")
+    t0 = _hbm_start()
     call("segk_upsample_fwd", _ptr(src), _dt(src), ld, N, C, Hi, Wi, _ptr(dst), _dt(dst), dst_layout, out_ld, Ho, Wo,
          _stream())
+    # algorithmic bytes: C channels of every source and destination pixel once
+    _hbm_stop("upsample_fwd", N * C * (Hi * Wi * src.element_size() + Ho * Wo * dst.element_size()), t0)
     return dst
 
 
@@ -608,8 +614,10 @@ def upsample_bwd(dout, dout_layout, N, C, Ho, Wo, din, cpad, Hi, Wi):
     din_ld = _pm(din)[0]
     n_ws = call("segk_upsample_bwd_workspace", dout_layout, N, C, Ho, Wi)
     ws = torch.empty((n_ws,), dtype=torch.float32, device=dout.device) if n_ws > 0 else None
+    t0 = _hbm_start()
     call("segk_upsample_bwd", _ptr(dout), _dt(dout), dout_layout, dout_ld, N, C, Ho, Wo, _ptr(din), _dt(din), din_ld,
          cpad, Hi, Wi, _ptr(ws), _stream())
+    _hbm_stop("upsample_bwd", N * (C * Ho * Wo * dout.element_size() + cpad * Hi * Wi * din.element_size()), t0)
     return din
 
 
@@ -628,8 +636,10 @@ def ce_fwd(logits, target, weight, ignore_index):
     partials = torch.empty((rows, 2), dtype=torch.float32, device=logits.device)
     lse = torch.empty((N, H, W), dtype=torch.float32, device=logits.device)
     sums = torch.empty((2,), dtype=torch.float32, device=logits.device)
+    t0 = _hbm_start()
     call("segk_ce_fwd", _ptr(logits), _ptr(target), _ptr(weight), N, K, H * W, ignore_index, _ptr(lse),
          _ptr(partials), _ptr(sums), _stream())
+    _hbm_stop("ce_fwd", _nbytes(logits, target, lse), t0)
     return sums, lse
 
 
@@ -638,8 +648,10 @@ def ce_bwd(logits, target, weight, lse, ignore_index, coef):
     _dev(logits, target, weight, lse, coef)
     N, K, H, W = logits.shape
     dl = torch.empty_like(logits)
+    t0 = _hbm_start()
     call("segk_ce_bwd", _ptr(logits), _ptr(target), _ptr(weight), _ptr(lse), N, K, H * W, ignore_index, _ptr(coef),
          _ptr(dl), _stream())
+    _hbm_stop("ce_bwd", _nbytes(logits, target, lse, dl), t0)
     return dl
 
 
@@ -662,8 +674,10 @@ def upsample_ce_fwd(low, N, Hi, Wi, target, weight, Ho, Wo, ignore_index):
     partials = torch.empty((rows, 2), dtype=torch.float32, device=low.device)
     lse = torch.empty((N, Ho, Wo), dtype=torch.float32, device=low.device)
     sums = torch.empty((2,), dtype=torch.float32, device=low.device)
+    t0 = _hbm_start()
     call("segk_upsample_ce_fwd", _ptr(low), _pm(low)[0], N, K, Hi, Wi, _ptr(target), _ptr(weight), Ho, Wo,
          ignore_index, _ptr(lse), _ptr(partials), _ptr(sums), _stream())
+    _hbm_stop("upsample_ce_fwd", N * Hi * Wi * K * 4 + _nbytes(target, lse), t0)
     return sums, lse
 
 
@@ -675,8 +689,10 @@ def upsample_ce_bwd(low, N, Hi, Wi, target, weight, lse, Ho, Wo, ignore_index, c
     n_ws = call("segk_upsample_bwd_workspace", NCHW, N, K, Ho, Wi)
     ws = torch.empty((n_ws,), dtype=torch.float32, device=low.device)
     dlow = torch.empty((N * Hi * Wi, cpad), dtype=torch.float32, device=low.device)
+    t0 = _hbm_start()
     call("segk_upsample_ce_bwd", _ptr(low), _pm(low)[0], N, K, Hi, Wi, _ptr(target), _ptr(weight), _ptr(lse), Ho, Wo,
          ignore_index, _ptr(coef), _ptr(ws), _ptr(dlow), cpad, cpad, _stream())
+    _hbm_stop("upsample_ce_bwd", N * Hi * Wi * K * 4 + _nbytes(target, lse, dlow), t0)
     return dlow
 
 
@@ -687,7 +703,9 @@ def upsample_argmax(low, N, Hi, Wi, Ho, Wo):
     if low.dtype != torch.float32 or low.dim() != 2 or low.shape[0] != N * Hi * Wi:
         raise ValueError("low-resolution logits must be a float32 pixel-major view [N*Hi*Wi, K]")
     pred = torch.empty((N, Ho, Wo), dtype=torch.int64, device=low.device)
+    t0 = _hbm_start()
     call("segk_upsample_argmax", _ptr(low), _pm(low)[0], N, low.shape[1], Hi, Wi, Ho, Wo, _ptr(pred), _stream())
+    _hbm_stop("upsample_argmax", N * Hi * Wi * low.shape[1] * 4 + _nbytes(pred), t0)
     return pred
 
 
@@ -697,7 +715,9 @@ def argmax(logits):
         raise ValueError("logits must be contiguous float32 NCHW")
     N, K, H, W = logits.shape
     pred = torch.empty((N, H, W), dtype=torch.int64, device=logits.device)
+    t0 = _hbm_start()
     call("segk_argmax", _ptr(logits), N, K, H * W, _ptr(pred), _stream())
+    _hbm_stop("argmax", _nbytes(logits, pred), t0)
     return pred
 
 
@@ -711,6 +731,8 @@ def confmat_accumulate(gt, pred, K, cm):
     if cm.dtype != torch.int64 or cm.numel() != K * K + 1 or not cm.is_contiguous():
         raise ValueError("cm must be contiguous int64 [K*K+1]")
     gt, pred = gt.contiguous(), pred.contiguous()
+    t0 = _hbm_start()
     call("segk_confmat", _ptr(gt), 1 if gt.dtype == torch.int64 else 0, _ptr(pred), gt.numel(), K, _ptr(cm),
          _stream())
+    _hbm_stop("confmat", _nbytes(gt, pred, cm), t0)   # the kernel's real input types: fp32 (or int64) labels, int64 predictions
     return cm

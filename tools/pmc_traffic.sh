@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_${tag}_$c
   timeout -s KILL 500 rocprofv3 --pmc $c -d /tmp/pmc_${tag}_$c -o p --output-format csv -- \
-    python3 "$repo/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-miopen-benchmark "$@" \
+    python3 "$repo/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-fp32 --no-torch-baseline --no-kernel-timing --no-miopen-benchmark "$@" \
     > "$repo/gpurun_out/bench_pmc_${tag}_$c.json"
   echo "pass $c done"
 done
