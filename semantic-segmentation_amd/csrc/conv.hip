@@ -18,10 +18,20 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <cstdio>
 #include "common.h"
 
 namespace segk {
+
+// Kernel-selection switches for experiments (tools/conv_bench.py, tools/conv_stamps.py) exist only in builds made
+// with -DSEGK_EXPERIMENTS (make EXPERIMENTS=1); the product library reads no environment variable and contains no
+// ablation kernel.
+#ifdef SEGK_EXPERIMENTS
+static const char* experiment(const char* name) { return getenv(name); }
+#else
+static constexpr const char* experiment(const char*) { return nullptr; }
+#endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -1055,10 +1065,37 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_dma_kernel(const WgradDev p
   }
 }
 
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// hipFuncSetAttribute is per device: remember, per kernel instantiation, the devices it has been done on (a bit per
+// device ordinal; two threads racing here both set the same value, which is harmless).
+struct LdsConfigured {
+  std::atomic<unsigned long long> devices{0ull};
+};
+
+template <typename K>
+static int set_lds(K kernel, int bytes, const char* name, LdsConfigured& done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) {
+    set_error("%s: hipGetDevice: %s", name, hipGetErrorString(e));
+    return SEGK_HIP_ERROR;
+  }
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (dev < 64 && (done.devices.load(std::memory_order_acquire) & bit)) return SEGK_OK;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    set_error("%s: hipFuncSetAttribute(%d bytes LDS): %s", name, bytes, hipGetErrorString(e));
+    return SEGK_HIP_ERROR;
+  }
+  if (dev < 64) done.devices.fetch_or(bit, std::memory_order_release);
+  return SEGK_OK;
+}
+
 // Launch the weight-gradient kernel; the 256 x 256 tile is used when the output channels fill it exactly.
 template <typename T>
 static int launch_wgrad(WgradDev& d, int batch, hipStream_t st, const char* name) {
-  static const char* force = getenv("SEGK_WGRAD_TILE");  // experiments: "small" (register-staged 128 tile) / "big" / "dma"
+  static const char* force = experiment("SEGK_WGRAD_TILE");  // experiments: "small" (register-staged 128 tile) / "big" / "dma"
   // The 256 x 256 tile when the output channels fill it exactly and the last input-channel tile is more than half
   // full (320 input channels would run a second tile that is a quarter full); otherwise the 128 x 128 tile, for
   // bf16 the LDS-DMA one.
@@ -1087,26 +1124,15 @@ static int launch_wgrad(WgradDev& d, int batch, hipStream_t st, const char* name
   }
   const int lds = 4 * 16384 * (big ? 2 : 1);
   int rc;
+  static LdsConfigured configured_big, configured_small;  // per instantiation
   if (big) {
-    rc = set_lds(conv_wgrad_kernel<T, 2>, lds, name);
+    rc = set_lds(conv_wgrad_kernel<T, 2>, lds, name, configured_big);
     if (rc != SEGK_OK) return rc;
     conv_wgrad_kernel<T, 2><<<dim3((unsigned)blocks, (unsigned)batch), CONV_THREADS * 2, lds, st>>>(d);
   } else {
-    rc = set_lds(conv_wgrad_kernel<T, 1>, lds, name);
+    rc = set_lds(conv_wgrad_kernel<T, 1>, lds, name, configured_small);
     if (rc != SEGK_OK) return rc;
     conv_wgrad_kernel<T, 1><<<dim3((unsigned)blocks, (unsigned)batch), CONV_THREADS, lds, st>>>(d);
-  }
-  return SEGK_OK;
-}
-
-static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
-
-template <typename K>
-static int set_lds(K kernel, int bytes, const char* name) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (e != hipSuccess) {
-    set_error("%s: hipFuncSetAttribute(%d bytes LDS): %s", name, bytes, hipGetErrorString(e));
-    return SEGK_HIP_ERROR;
   }
   return SEGK_OK;
 }
@@ -1115,12 +1141,9 @@ static int set_lds(K kernel, int bytes, const char* name) {
 template <typename T, int BKB, typename TO, typename G, int ABL = 0>
 static int launch_fwd(ConvDev& d, hipStream_t st, int batch = 1, long long px_tiles = -1) {
   const int lds = 2 * (G::BCO + G::BPX) * BKB;
-  static bool configured = false;  // per instantiation
-  if (!configured) {
-    int rc = set_lds(conv_fwd_kernel<T, BKB, TO, G, ABL>, lds, "conv_fwd");
-    if (rc != SEGK_OK) return rc;
-    configured = true;
-  }
+  static LdsConfigured configured;  // per instantiation
+  int rc = set_lds(conv_fwd_kernel<T, BKB, TO, G, ABL>, lds, "conv_fwd", configured);
+  if (rc != SEGK_OK) return rc;
   d.n_tiles = ceil_div(d.Cout, G::BCO);
   if (px_tiles < 0) px_tiles = (d.M - d.m_begin + G::BPX - 1) / G::BPX;
   const long long blocks = px_tiles * d.n_tiles;
@@ -1309,12 +1332,9 @@ __global__ __launch_bounds__(256, PX == 128 ? 3 : 2) void conv_fwd_dma_kernel(co
 template <typename TO, int PX = 128>
 static int launch_dma(ConvDev& d, hipStream_t st, int batch = 1, long long px_tiles = -1) {
   constexpr int lds = (128 + PX) * 128;
-  static bool configured = false;  // per instantiation
-  if (!configured) {
-    int rc = set_lds(conv_fwd_dma_kernel<TO, PX>, lds, "conv_fwd_dma");
-    if (rc != SEGK_OK) return rc;
-    configured = true;
-  }
+  static LdsConfigured configured;  // per instantiation
+  int rc = set_lds(conv_fwd_dma_kernel<TO, PX>, lds, "conv_fwd_dma", configured);
+  if (rc != SEGK_OK) return rc;
   d.n_tiles = ceil_div(d.Cout, 128);
   if (px_tiles < 0) px_tiles = (d.M - d.m_begin + PX - 1) / PX;
   const long long blocks = px_tiles * d.n_tiles;
@@ -1329,24 +1349,21 @@ static int launch_dma(ConvDev& d, hipStream_t st, int batch = 1, long long px_ti
 // the 128 x 256 LDS-DMA tile serves the big-tile plan for bf16; SEGK_CONV_BIGDMA=0 brings back the register-staged
 // 256 x 256 tile
 static bool use_bigdma() {
-  static const char* e = getenv("SEGK_CONV_BIGDMA");
+  static const char* e = experiment("SEGK_CONV_BIGDMA");
   return !(e && e[0] == '0');
 }
 
 // default for bf16 operands with 128-byte K rows; SEGK_CONV_DMA=0 falls back to the register-staged small tile
 static bool use_dma() {
-  static const char* e = getenv("SEGK_CONV_DMA");
+  static const char* e = experiment("SEGK_CONV_DMA");
   return !(e && e[0] == '0');
 }
 
 template <typename TO, int ABL = 0>
 static int launch_pipe(ConvDev& d, hipStream_t st, int batch = 1) {
-  static bool configured = false;  // per instantiation
-  if (!configured) {
-    int rc = set_lds(conv_fwd_pipe_kernel<TO, ABL>, PP_LDS, "conv_fwd_pipe");
-    if (rc != SEGK_OK) return rc;
-    configured = true;
-  }
+  static LdsConfigured configured;  // per instantiation
+  int rc = set_lds(conv_fwd_pipe_kernel<TO, ABL>, PP_LDS, "conv_fwd_pipe", configured);
+  if (rc != SEGK_OK) return rc;
   d.n_tiles = d.Cout / TilePipe::BCO;
   const long long blocks = ((d.M + TilePipe::BPX - 1) / TilePipe::BPX) * d.n_tiles;
   if (blocks >= 2147483647LL) {
@@ -1361,7 +1378,7 @@ static int launch_pipe(ConvDev& d, hipStream_t st, int batch = 1) {
 // register-staged big tile, because both are bound by the rate at which a CU can pull operand tiles through its
 // vector L1 (about 20 bytes per cycle), not by staging registers or by the barrier structure.
 static bool use_pipe() {
-  static const char* e = getenv("SEGK_CONV_PIPE");
+  static const char* e = experiment("SEGK_CONV_PIPE");
   return e && e[0] == '1';
 }
 
@@ -1380,7 +1397,7 @@ static int cu_count() {
 static bool use_big_tile(const ConvDev& d, bool wide, int batch = 1) {
   // the big tile needs 128-byte K rows, full 256-channel tiles and enough tiles to fill 256 CUs twice
   if (!wide || d.Cout % TileBig::BCO != 0) return false;
-  static const char* force = getenv("SEGK_CONV_TILE");  // experiments: "small" / "big"
+  static const char* force = experiment("SEGK_CONV_TILE");  // experiments: "small" / "big"
   if (force && force[0] == 's') return false;
   if (force && (force[0] == 'b' || force[0] == 'h')) return true;
   // Rounds of workgroups each geometry needs (a last round under 15 % full is not counted: the CUs drift apart
@@ -1412,7 +1429,7 @@ static TilePlan plan_tiles(const ConvDev& d, bool wide, int batch) {
   pl.big = use_big_tile(d, wide, batch);
   pl.tail = false;
   pl.main_tiles = (d.M + (pl.big ? TileBig::BPX : TileSmall::BPX) - 1) / (pl.big ? TileBig::BPX : TileSmall::BPX);
-  static const char* e = getenv("SEGK_CONV_TAIL");
+  static const char* e = experiment("SEGK_CONV_TAIL");
   if (pl.big && batch == 1 && !use_pipe() && !(e && e[0] == '0')) {
     const long long n_co = d.Cout / TileBig::BCO, blocks = pl.main_tiles * n_co, slots = cu_count();
     const long long rounds = blocks / slots, rem = blocks % slots;
@@ -1509,7 +1526,8 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
   const bool big = plan.big;
   d.stat_batch = (long long)plan_stat_rows(d, plan) * 2 * d.Cout;
   hipStream_t st = (hipStream_t)stream;
-  static const char* abl = getenv("SEGK_CONV_ABL");
+#ifdef SEGK_EXPERIMENTS
+  static const char* abl = experiment("SEGK_CONV_ABL");
   if (abl && abl[0] && big && use_pipe() && a->dtype == SEGK_BF16 && a->out_dtype == SEGK_BF16) {
     rc = abl[0] == '1' ? launch_pipe<bf16_t, 1>(d, st)
        : abl[0] == '2' ? launch_pipe<bf16_t, 2>(d, st)
@@ -1533,6 +1551,7 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
     SEGK_CHECK_LAUNCH("conv_fwd");
     return SEGK_OK;
   }
+#endif
 #define SEGK_LAUNCH(T, TO)                                                          \
   (big ? launch_fwd<T, 128, TO, TileBig>(d, st, batch)                              \
        : (wide ? launch_fwd<T, 128, TO, TileSmall>(d, st, batch) : launch_fwd<T, 64, TO, TileSmall>(d, st, batch)))
@@ -1564,8 +1583,10 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
 #undef SEGK_SPLIT
   } else if (a->dtype == SEGK_BF16 && big && use_bigdma()) {
     rc = a->out_dtype == SEGK_BF16 ? launch_dma<bf16_t, 256>(d, st, batch) : launch_dma<float, 256>(d, st, batch);
+#ifdef SEGK_EXPERIMENTS
   } else if (a->dtype == SEGK_BF16 && big && use_pipe()) {
     rc = a->out_dtype == SEGK_BF16 ? launch_pipe<bf16_t>(d, st, batch) : launch_pipe<float>(d, st, batch);
+#endif
   } else if (a->dtype == SEGK_BF16) {
     rc = a->out_dtype == SEGK_BF16 ? SEGK_LAUNCH(bf16_t, bf16_t) : SEGK_LAUNCH(bf16_t, float);
   } else {
@@ -1659,16 +1680,19 @@ extern "C" int segk_gemm_nt(const segk_gemm_args* a, segk_stream_t stream) {
   d.bias = nullptr; d.img_bias = nullptr; d.stat = nullptr;
   const long long big_tiles = (long long)ceil_div(a->M, TileBig::BPX) * (a->N / TileBig::BCO) * a->batch;
   const bool big = wide && a->N % TileBig::BCO == 0 && big_tiles >= 512;
-  static const char* gemm_env = getenv("SEGK_GEMM_DMA");
+  static const char* gemm_env = experiment("SEGK_GEMM_DMA");
   const bool gemm_dma = !(gemm_env && gemm_env[0] == '0');
   hipStream_t st = (hipStream_t)stream;
   int rc;
 #define SEGK_LAUNCH(T, TO)                                                                   \
   (big ? launch_fwd<T, 128, TO, TileBig>(d, st, a->batch)                                    \
        : (wide ? launch_fwd<T, 128, TO, TileSmall>(d, st, a->batch) : launch_fwd<T, 64, TO, TileSmall>(d, st, a->batch)))
+#ifdef SEGK_EXPERIMENTS
   if (a->dtype == SEGK_BF16 && big && use_pipe()) {
     rc = a->c_dtype == SEGK_BF16 ? launch_pipe<bf16_t>(d, st, a->batch) : launch_pipe<float>(d, st, a->batch);
-  } else if (a->dtype == SEGK_BF16 && big && use_bigdma() && gemm_dma) {
+  } else
+#endif
+  if (a->dtype == SEGK_BF16 && big && use_bigdma() && gemm_dma) {
     rc = a->c_dtype == SEGK_BF16 ? launch_dma<bf16_t, 256>(d, st, a->batch) : launch_dma<float, 256>(d, st, a->batch);
   } else if (a->dtype == SEGK_BF16 && wide && !big && use_dma() && gemm_dma) {
     rc = a->c_dtype == SEGK_BF16 ? launch_dma<bf16_t>(d, st, a->batch) : launch_dma<float>(d, st, a->batch);

@@ -3,7 +3,7 @@
 Replaces /root/reference/modeling/sync_batchnorm/batchnorm.py:38-126: constructor signature, class
 hierarchy (subclass of torch's _BatchNorm, not of nn.BatchNorm2d), parameters and buffers are the
 same, so state_dicts interchange.  Statistics are global over all ranks of the default process group:
-each rank reduces sum / sum-of-squares of its shard with a HIP kernel, one all-reduce of a [2C+1] fp32
+each rank reduces sum / sum-of-squares of its shard with a HIP kernel, one all-reduce of a [2C+1] fp64
 vector replaces the master/slave queue hand-off (comm.py:97-125) plus ReduceAddCoalesced/Broadcast
 (batchnorm.py:101-105), and every rank derives mean, inv_std and the running statistics itself.  With a
 single rank, or in eval mode, the arithmetic is F.batch_norm's (batchnorm.py:50-53).

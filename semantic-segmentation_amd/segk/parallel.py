@@ -6,7 +6,7 @@ computes one loss on the gathered batch (/root/reference/train.py:148-153) and l
 reduce-add gradients.  Here every rank owns its shard and three collectives (RCCL through
 torch.distributed's "nccl" backend on GPUs, "gloo" in CPU tests) make the result equal to one device
 running the whole batch:
-  1. SyncBN forward/backward: all-reduce(SUM) of a [2C+1] fp32 vector per layer;
+  1. SyncBN forward/backward: all-reduce(SUM) of a [2C+1] fp64 vector per layer;
   2. loss: all-reduce(SUM) of [sum w*nll, sum w, batch] so each rank divides by the global normaliser;
   3. gradients: bucketed all-reduce(SUM) (each rank already divided by the global normaliser).
 """

@@ -1,5 +1,10 @@
 """LR_Scheduler with the call shape of /root/reference/utils/lr_scheduler.py:32-73: poly / cos / step,
-optional warm-up, first parameter group at lr and every further group at 10x lr."""
+optional warm-up, first parameter group at lr and every further group at 10x lr.
+
+The schedule formulas and the 1x / 10x group rule are those of the reference file, which carries the notice
+"Created by: Hang Zhang, ECE Department, Rutgers University, zhang.hang@rutgers.edu, Copyright (c) 2017; this
+source code is licensed under the MIT-style license found in the LICENSE file in the root directory of this
+source tree" (PyTorch-Encoding); this file is an independent restatement of that interface."""
 import math
 
 
