@@ -64,6 +64,12 @@ int segk_pm_to_nchw(const void* src, int src_dtype, int src_ld, float* dst, int 
  * Padding columns are written as zeros. */
 int segk_pack_weight(const float* w_oihw, void* dst, int dst_dtype, int Cout, int Cin, int R, int transpose,
                      segk_stream_t stream);
+/* The same from a weight of either dtype in any dense layout, given by the element strides of its output-channel,
+ * input-channel and tap (r*R + s) indices: contiguous OIHW is (Cin*R*R, R*R, 1), a channels_last nn.Conv2d weight
+ * (the feeder's bottleneck convolutions, newmodeling/backbone/resnet101_2.py:19-21, under a channels_last model) is
+ * (R*R*Cin, 1, Cin). */
+int segk_pack_weight_strided(const void* w, int w_dtype, long long s_co, long long s_ci, long long s_tap, void* dst,
+                             int dst_dtype, int Cout, int Cin, int R, int transpose, segk_stream_t stream);
 
 typedef struct {
   const void* in;  /* [M][in_ld] activations, args.dtype */
@@ -123,6 +129,11 @@ int segk_conv_wgrad(const segk_wgrad_args* a, segk_stream_t stream);
  * dw[co][ci][r][s] = sum_split slabs[split][tap][ci][co], co < Cout_true, ci < Cin_true. */
 int segk_wgrad_finish(const float* slabs, int splits, int R, int Cin, int Cout, float* dw_oihw, int Cout_true,
                       int Cin_true, segk_stream_t stream);
+/* The same into a gradient tensor of either dtype laid out like its weight (strides as segk_pack_weight_strided):
+ * autograd wants the gradient of a bf16 channels_last parameter in that dtype and layout. */
+int segk_wgrad_finish_strided(const float* slabs, int splits, int R, int Cin, int Cout, void* dw, int dw_dtype,
+                              long long s_co, long long s_ci, long long s_tap, int Cout_true, int Cin_true,
+                              segk_stream_t stream);
 
 /* ---- batched matrix products (attention: modeling/damm_cam_pam.py) --------------------------- */
 typedef struct {

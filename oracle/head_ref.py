@@ -182,11 +182,20 @@ def _load_feeder_module():
 
 class RefDeepLab(nn.Module):
     def __init__(self, backbone="resnet", output_stride=16, num_classes=21, BatchNorm=nn.BatchNorm2d,
-                 feeder="resnet101"):
+                 feeder="resnet101", mask_feeder_relus=False):
+        """mask_feeder_relus: the feeder's ReLUs (stem, and the three of every bottleneck block, in evaluation order)
+        also take externally supplied activation patterns (use_relu_masks), for comparisons with an implementation
+        that reports the pattern of every ReLU of the network."""
         super().__init__()
         fm = _load_feeder_module()
         ctor = fm.ResNet101 if feeder == "resnet101" else fm.ResNet50
         self.backbone = ctor(output_stride, BatchNorm, pretrained=False)
+        if mask_feeder_relus:
+            for m in self.backbone.modules():
+                if isinstance(getattr(m, "relu", None), nn.ReLU):
+                    m.relu = _ReLU()
+                    if hasattr(m, "relu2"):
+                        m.relu2 = m.relu
         self.aspp = RefASPP(backbone, output_stride, BatchNorm)
         self.decoder = RefDecoder(num_classes, backbone, BatchNorm)
 

@@ -64,28 +64,53 @@ __global__ __launch_bounds__(256) void pm_to_nchw_kernel(const TS* __restrict__ 
 
 // dst[tapd][row][k]: transpose == 0: row = co, k = ci, tapd = tap; transpose == 1: row = ci, k = co,
 // tapd = taps-1-tap.  k runs to Ck (multiple of 32); the tail is zero.
-template <typename TD>
-__global__ void pack_weight_kernel(const float* __restrict__ w, TD* __restrict__ dst, int Cout, int Cin, int taps,
-                                   int rows, int kdim, int Ck, int transpose, long long total) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  int k = (int)(i % Ck);
-  long long t = i / Ck;
-  int row = (int)(t % rows);
-  int tapd = (int)(t / rows);
-  float v = 0.f;
-  if (k < kdim) {
-    int co = transpose ? k : row;
-    int ci = transpose ? row : k;
-    int tap = transpose ? (taps - 1 - tapd) : tapd;
-    v = w[((size_t)co * Cin + ci) * taps + tap];
+// The source is any dense layout of the [Cout][Cin][taps] weight given by three element strides (OIHW: s_tap = 1,
+// channels_last: s_ci = 1).  One block moves a 32(co) x 32(ci) patch of every tap through LDS: it reads in the
+// source's own order (runs of 32*taps or 32 elements) and writes runs of 32 along k.
+template <typename TS, typename TD, int TAPS>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const TS* __restrict__ w, long long s_co, long long s_ci,
+                                                           long long s_tap, TD* __restrict__ dst, int Cout, int Cin,
+                                                           int rows, int Ck, int transpose) {
+  __shared__ float tile[TAPS][32][33];
+  const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
+  constexpr int PATCH = 32 * 32 * TAPS;
+  const bool tap_fastest = s_tap == 1;
+  for (int i = threadIdx.x; i < PATCH; i += 256) {
+    int co_l, ci_l, tap;
+    if (tap_fastest) {           // (co, ci, tap): tap then ci contiguous in the source
+      co_l = i / (32 * TAPS);
+      const int rem = i - co_l * (32 * TAPS);
+      ci_l = rem / TAPS;
+      tap = rem - ci_l * TAPS;
+    } else {                     // (co, tap, ci): ci contiguous in the source
+      co_l = i / (32 * TAPS);
+      const int rem = i - co_l * (32 * TAPS);
+      tap = rem >> 5;
+      ci_l = rem & 31;
+    }
+    const int co = co0 + co_l, ci = ci0 + ci_l;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) v = Elem<TS>::load(w + co * s_co + ci * s_ci + tap * s_tap);
+    tile[tap][co_l][ci_l] = v;
   }
-  Elem<TD>::store(dst + i, v);
+  __syncthreads();
+  for (int i = threadIdx.x; i < PATCH; i += 256) {
+    const int k_l = i & 31, r_l = (i >> 5) & 31, tap = i >> 10;
+    // transpose == 0: row = co, k = ci;  transpose == 1: row = ci, k = co, taps reversed
+    const int row = (transpose ? ci0 : co0) + r_l, k = (transpose ? co0 : ci0) + k_l;
+    if (row < rows && k < Ck) {
+      const int tapd = transpose ? TAPS - 1 - tap : tap;
+      const float v = transpose ? tile[tap][k_l][r_l] : tile[tap][r_l][k_l];
+      Elem<TD>::store(dst + ((size_t)tapd * rows + row) * Ck + k, v);
+    }
+  }
 }
 
 // dw[co][ci][tap] = sum_s slabs[s][tap][ci][co]
+template <typename TD>
 __global__ void wgrad_finish_kernel(const float* __restrict__ slabs, int splits, int taps, int Cin, int Cout,
-                                    float* __restrict__ dw, int Cout_true, int Cin_true) {
+                                    TD* __restrict__ dw, long long s_co, long long s_ci, long long s_tap,
+                                    int Cout_true, int Cin_true) {
   // tile transpose over (ci, co) for one tap: reads run along co, writes along (ci, tap)
   __shared__ float tile[32][33];
   const int tap = blockIdx.z;
@@ -106,7 +131,7 @@ __global__ void wgrad_finish_kernel(const float* __restrict__ slabs, int splits,
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int co = co0 + ty + i * 8, ci = ci0 + tx;
-    if (co < Cout_true && ci < Cin_true) dw[((size_t)co * Cin_true + ci) * taps + tap] = tile[tx][ty + i * 8];
+    if (co < Cout_true && ci < Cin_true) Elem<TD>::store(dw + co * s_co + ci * s_ci + tap * s_tap, tile[tx][ty + i * 8]);
   }
 }
 
@@ -148,34 +173,71 @@ extern "C" int segk_pm_to_nchw(const void* src, int src_dtype, int src_ld, float
   return SEGK_OK;
 }
 
-extern "C" int segk_pack_weight(const float* w, void* dst, int dst_dtype, int Cout, int Cin, int R, int transpose,
-                                segk_stream_t stream) {
-  SEGK_REQUIRE(w && dst && valid_dtype(dst_dtype), "pack_weight: null pointer or bad dtype");
+template <typename TS, typename TD>
+static void launch_pack(const void* w, long long s_co, long long s_ci, long long s_tap, void* dst, int Cout, int Cin,
+                        int taps, int rows, int Ck, int transpose, hipStream_t st) {
+  // patches cover co up to Cout (or up to Ck when co is the padded k index) and ci likewise
+  dim3 grid(ceil_div(transpose ? Ck : Cout, 32), ceil_div(transpose ? Cin : Ck, 32));
+  if (taps == 9)
+    pack_weight_kernel<TS, TD, 9><<<grid, 256, 0, st>>>((const TS*)w, s_co, s_ci, s_tap, (TD*)dst, Cout, Cin, rows, Ck, transpose);
+  else
+    pack_weight_kernel<TS, TD, 1><<<grid, 256, 0, st>>>((const TS*)w, s_co, s_ci, s_tap, (TD*)dst, Cout, Cin, rows, Ck, transpose);
+}
+
+extern "C" int segk_pack_weight_strided(const void* w, int w_dtype, long long s_co, long long s_ci, long long s_tap,
+                                        void* dst, int dst_dtype, int Cout, int Cin, int R, int transpose,
+                                        segk_stream_t stream) {
+  SEGK_REQUIRE(w && dst && valid_dtype(dst_dtype) && valid_dtype(w_dtype), "pack_weight: null pointer or bad dtype");
   SEGK_REQUIRE(Cout > 0 && Cin > 0 && (R == 1 || R == 3), "pack_weight: bad shape Cout=%d Cin=%d R=%d", Cout, Cin, R);
+  SEGK_REQUIRE(s_co > 0 && s_ci > 0 && s_tap > 0, "pack_weight: strides must be positive");
   const int taps = R * R;
   const int rows = transpose ? Cin : Cout;
   const int kdim = transpose ? Cout : Cin;
   const int Ck = round_up(kdim, 32);
-  const long long total = (long long)taps * rows * Ck;
-  const int grid = ceil_div(total, 256);
+  SEGK_REQUIRE(ceil_div(transpose ? Cin : Ck, 32) <= 65535, "pack_weight: too many input channels");
   hipStream_t st = (hipStream_t)stream;
-  if (dst_dtype == SEGK_BF16)
-    pack_weight_kernel<bf16_t><<<grid, 256, 0, st>>>(w, (bf16_t*)dst, Cout, Cin, taps, rows, kdim, Ck, transpose, total);
-  else
-    pack_weight_kernel<float><<<grid, 256, 0, st>>>(w, (float*)dst, Cout, Cin, taps, rows, kdim, Ck, transpose, total);
+  if (w_dtype == SEGK_BF16) {
+    if (dst_dtype == SEGK_BF16) launch_pack<bf16_t, bf16_t>(w, s_co, s_ci, s_tap, dst, Cout, Cin, taps, rows, Ck, transpose, st);
+    else launch_pack<bf16_t, float>(w, s_co, s_ci, s_tap, dst, Cout, Cin, taps, rows, Ck, transpose, st);
+  } else {
+    if (dst_dtype == SEGK_BF16) launch_pack<float, bf16_t>(w, s_co, s_ci, s_tap, dst, Cout, Cin, taps, rows, Ck, transpose, st);
+    else launch_pack<float, float>(w, s_co, s_ci, s_tap, dst, Cout, Cin, taps, rows, Ck, transpose, st);
+  }
   SEGK_CHECK_LAUNCH("pack_weight");
+  return SEGK_OK;
+}
+
+extern "C" int segk_pack_weight(const float* w, void* dst, int dst_dtype, int Cout, int Cin, int R, int transpose,
+                                segk_stream_t stream) {
+  const long long taps = (long long)R * R;
+  return segk_pack_weight_strided(w, SEGK_F32, (long long)Cin * taps, taps, 1, dst, dst_dtype, Cout, Cin, R, transpose,
+                                  stream);
+}
+
+extern "C" int segk_wgrad_finish_strided(const float* slabs, int splits, int R, int Cin, int Cout, void* dw,
+                                         int dw_dtype, long long s_co, long long s_ci, long long s_tap, int Cout_true,
+                                         int Cin_true, segk_stream_t stream) {
+  SEGK_REQUIRE(slabs && dw && valid_dtype(dw_dtype), "wgrad_finish: null pointer or bad dtype");
+  SEGK_REQUIRE(splits >= 1 && (R == 1 || R == 3) && Cin > 0 && Cout > 0 && Cout_true > 0 && Cout_true <= Cout &&
+                   Cin_true > 0 && Cin_true <= Cin,
+               "wgrad_finish: bad shape splits=%d R=%d Cin=%d Cout=%d (%d,%d)", splits, R, Cin, Cout, Cout_true,
+               Cin_true);
+  SEGK_REQUIRE(s_co > 0 && s_ci > 0 && s_tap > 0, "wgrad_finish: strides must be positive");
+  dim3 grid(ceil_div(Cout, 32), ceil_div(Cin, 32), R * R);
+  hipStream_t st = (hipStream_t)stream;
+  if (dw_dtype == SEGK_BF16)
+    wgrad_finish_kernel<bf16_t><<<grid, 256, 0, st>>>(slabs, splits, R * R, Cin, Cout, (bf16_t*)dw, s_co, s_ci, s_tap,
+                                                      Cout_true, Cin_true);
+  else
+    wgrad_finish_kernel<float><<<grid, 256, 0, st>>>(slabs, splits, R * R, Cin, Cout, (float*)dw, s_co, s_ci, s_tap,
+                                                     Cout_true, Cin_true);
+  SEGK_CHECK_LAUNCH("wgrad_finish");
   return SEGK_OK;
 }
 
 extern "C" int segk_wgrad_finish(const float* slabs, int splits, int R, int Cin, int Cout, float* dw, int Cout_true,
                                  int Cin_true, segk_stream_t stream) {
-  SEGK_REQUIRE(slabs && dw, "wgrad_finish: null pointer");
-  SEGK_REQUIRE(splits >= 1 && (R == 1 || R == 3) && Cin > 0 && Cout > 0 && Cout_true > 0 && Cout_true <= Cout &&
-                   Cin_true > 0 && Cin_true <= Cin,
-               "wgrad_finish: bad shape splits=%d R=%d Cin=%d Cout=%d (%d,%d)", splits, R, Cin, Cout, Cout_true,
-               Cin_true);
-  dim3 grid(ceil_div(Cout, 32), ceil_div(Cin, 32), R * R);
-  wgrad_finish_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(slabs, splits, R * R, Cin, Cout, dw, Cout_true, Cin_true);
-  SEGK_CHECK_LAUNCH("wgrad_finish");
-  return SEGK_OK;
+  const long long taps = (long long)R * R;
+  return segk_wgrad_finish_strided(slabs, splits, R, Cin, Cout, dw, SEGK_F32, (long long)Cin_true * taps, taps, 1,
+                                   Cout_true, Cin_true, stream);
 }

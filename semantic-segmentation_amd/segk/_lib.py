@@ -58,10 +58,13 @@ SIGNATURES = {
     "segk_nchw_to_pm": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "segk_pm_to_nchw": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "segk_pack_weight": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "segk_pack_weight_strided": [c_void_p, c_int, c_ll, c_ll, c_ll, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "segk_conv_fwd": [ctypes.POINTER(ConvArgs), c_void_p],
     "segk_conv_stat_rows": [ctypes.POINTER(ConvArgs)],
     "segk_conv_wgrad": [ctypes.POINTER(WgradArgs), c_void_p],
     "segk_wgrad_finish": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
+    "segk_wgrad_finish_strided": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_ll, c_ll, c_ll, c_int, c_int,
+                                  c_void_p],
     "segk_gemm_nt": [ctypes.POINTER(GemmArgs), c_void_p],
     "segk_gemm_tn": [ctypes.POINTER(GemmTnArgs), c_void_p],
     "segk_gemm_tn_finish": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_ll, c_int, c_int, c_int, c_void_p],

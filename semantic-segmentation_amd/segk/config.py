@@ -3,7 +3,7 @@ import contextlib
 
 import torch
 
-_state = {"compute_dtype": torch.float32, "legacy_clamp_eps": False}
+_state = {"compute_dtype": torch.float32, "legacy_clamp_eps": False, "feeder_conv": "auto"}
 
 
 def set_compute_dtype(dtype):
@@ -38,3 +38,30 @@ def set_legacy_clamp_eps(flag):
 
 def legacy_clamp_eps():
     return _state["legacy_clamp_eps"]
+
+
+def set_feeder_conv(mode):
+    """Which kernels run the feeder's stride-1 3x3 bottleneck convolutions with 256 or more channels
+    (/root/reference/newmodeling/backbone/resnet101_2.py:19-21; ResNet layers 3 and 4) together with the batch norm
+    and ReLU behind them, when that batch norm is a SynchronizedBatchNorm2d:
+      "auto"  (default) the HIP implicit-GEMM kernels when the activation already is pixel-major memory
+              (a channels_last feeder, e.g. under bf16 autocast), PyTorch-ROCm / MIOpen otherwise;
+      "hip"   the HIP kernels always (NCHW activations are transposed on the way in and out);
+      "torch" never."""
+    if mode not in ("auto", "hip", "torch"):
+        raise ValueError("feeder_conv mode must be 'auto', 'hip' or 'torch'")
+    _state["feeder_conv"] = mode
+
+
+def feeder_conv():
+    return _state["feeder_conv"]
+
+
+@contextlib.contextmanager
+def feeder_conv_as(mode):
+    old = _state["feeder_conv"]
+    set_feeder_conv(mode)
+    try:
+        yield
+    finally:
+        _state["feeder_conv"] = old

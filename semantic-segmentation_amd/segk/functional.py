@@ -21,8 +21,9 @@ from ._lib import NCHW, PM
 
 _BN_TYPES = (torch.nn.modules.batchnorm._BatchNorm,)
 
-# Test hook: when set to a list, every fused conv->BN->ReLU unit appends (output view, (N,H,W)) so a test can
-# read the activation pattern the kernels produced.  None in normal operation.
+# Test hook: when set to a list, every fused conv->BN->ReLU unit appends (pixel-major output view, (N,H,W)) and
+# every stand-alone batch norm with a fused ReLU appends (NCHW-shaped output, None), so a test can read the
+# activation pattern the kernels produced.  None in normal operation.
 CAPTURE = None
 
 
@@ -186,9 +187,10 @@ def unit_finish(x, raw, stats, weight, R, dil, geom, spec, gamma, beta, out, rel
     return rec
 
 
-def unit_backward(rec, dz, need_dw=True):
+def unit_backward(rec, dz, need_dw=True, dw_like=None):
     """dz: pixel-major gradient w.r.t. the unit's output.  Returns (dy [M, Cout rounded up to 32] with zero
-    padding = gradient w.r.t. the conv output, dW, dgamma, dbeta)."""
+    padding = gradient w.r.t. the conv output, dW, dgamma, dbeta).  dw_like: a weight whose dtype and strides dW
+    takes (default: contiguous fp32)."""
     N, H, W = rec.geom
     M = N * H * W
     C = rec.Cout
@@ -204,7 +206,8 @@ def unit_backward(rec, dz, need_dw=True):
     dw = None
     if need_dw:
         c16 = ops.round_up(C, 16)
-        dw = ops.conv_wgrad(rec.x, dy[:, :c16] if c16 != cpad else dy, N, H, W, rec.R, rec.dil, C, rec.Cin)
+        dw = ops.conv_wgrad(rec.x, dy[:, :c16] if c16 != cpad else dy, N, H, W, rec.R, rec.dil, C, rec.Cin,
+                            like=dw_like)
     return dy, dw, dgamma, dbeta
 
 
@@ -578,6 +581,8 @@ class SyncBNFunction(torch.autograd.Function):
         else:
             y = torch.empty_like(xv)
             ops.bn_apply(xv, y, coef, NCHW, relu)
+        if CAPTURE is not None and relu:
+            CAPTURE.append((y, None))   # already NCHW-shaped
         # without a residual the ReLU pattern is recomputed from x*scale + shift; with one it is read from y
         act = pm_view_of(y) if (rv is not None and relu) else None
         ctx.saved = (xv, coef, layout, spec.training, spec.sync, x.dtype, shape, relu, act, rv is not None)
@@ -613,6 +618,48 @@ class SyncBNFunction(torch.autograd.Function):
         if not ctx.affine:
             dgamma = dbeta = None
         return dx, dgamma, dbeta, None, None, dres
+
+
+# ------------------------------------------------- feeder conv + BN + ReLU ----
+class ConvBNReLUFunction(torch.autograd.Function):
+    """relu(bn(conv3x3(x))) of a feeder bottleneck block (newmodeling/backbone/resnet101_2.py:19-21 and
+    Bottleneck.forward, conv2 -> bn2 -> relu; stride 1, padding = dilation) as one unit on the implicit-GEMM
+    kernels: the convolution's epilogue emits the batch-norm statistics, one pass applies BN + ReLU; backward is the
+    BN reduce / apply pair, the weight-gradient GEMM and the data-gradient convolution.  Operands take the
+    activation's dtype (bf16 under autocast); the convolution output is kept in that dtype as well, like the
+    PyTorch path it replaces.  The weight may be fp32 or bf16, contiguous or channels_last; its gradient comes back
+    in the weight's own dtype and layout."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, conv, bn):
+        N, Cin, H, W = x.shape
+        R, dil = conv.kernel_size[0], conv.dilation[0]
+        cd = torch.bfloat16 if (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()) else torch.float32
+        xv = _padded_input(to_pm(x, cd))
+        Cout = weight.shape[0]
+        M = N * H * W
+        spec = _BNSpec(bn)
+        raw = torch.empty((M, Cout), dtype=cd, device=x.device)
+        stats = ops.conv_fwd([(xv, ops.pack_weight(weight.detach(), cd), R, dil)], N, H, W, Cout, raw,
+                             want_stats=spec.training, true_ck=[Cin])
+        y = torch.empty((N, Cout, H, W), dtype=cd, device=x.device, memory_format=torch.channels_last)
+        rec = unit_finish(xv, raw, stats, weight, R, dil, (N, H, W), spec, gamma, beta, pm_view_of(y), relu=True)
+        ctx.rec, ctx.x = rec, x
+        if pm_view_of(x) is None or x.is_contiguous():   # hand an NCHW caller an NCHW tensor back
+            y = y.contiguous()
+        return y if y.dtype == x.dtype or torch.is_autocast_enabled() else y.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        rec, x = ctx.rec, ctx.x
+        N, H, W = rec.geom
+        dy, dw, dgamma, dbeta = unit_backward(rec, to_pm(g, rec.x.dtype), need_dw=ctx.needs_input_grad[1],
+                                              dw_like=rec.weight)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxp = dgrad([(dy, rec.weight, rec.R, rec.dil)], rec.geom, rec.Cin, grad_dtype_for(x))
+            dx = grad_like(x, dxp, N, H, W)
+        return dx, dw, dgamma, dbeta, None, None
 
 
 # ------------------------------------------------------------ plain conv ----

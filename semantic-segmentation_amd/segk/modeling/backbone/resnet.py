@@ -42,13 +42,19 @@ class Bottleneck(nn.Module):
         self.conv3 = _conv(planes, planes * self.expansion, 1)
         self.bn3 = BatchNorm(planes * self.expansion)
         self.relu = nn.ReLU(inplace=True)
+        self.relu2 = self.relu   # the ReLU behind bn2 under a name of its own (same module): parity tests swap it
         self.downsample = downsample
         self.stride = stride
         self.dilation = dilation
 
     def forward(self, x):
         y = _bn_relu(self.bn1, self.relu, self.conv1(x))
-        y = _bn_relu(self.bn2, self.relu, self.conv2(y))
+        # batch-norm classes that can run the 3x3 convolution, their own statistics and the ReLU as one unit do so
+        unit = getattr(self.bn2, "forward_conv_relu", None)
+        if unit is not None and self.bn2.can_fuse_conv(self.conv2, y):
+            y = unit(self.conv2, y)
+        else:
+            y = _bn_relu(self.bn2, self.relu2, self.conv2(y))
         y = self.conv3(y)
         # the projection runs after the main path: autograd then sums the gradients that
         # reach x in the same order as the reference does, which keeps training bit-identical

@@ -15,6 +15,14 @@ from ... import functional as SF
 __all__ = ["SynchronizedBatchNorm1d", "SynchronizedBatchNorm2d", "SynchronizedBatchNorm3d"]
 
 
+def conv_is_hip_eligible(conv):
+    """The static part of can_fuse_conv: layer-3 / layer-4 bottleneck 3x3 convolutions of a ResNet feeder."""
+    return (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.groups == 1 and conv.bias is None
+            and conv.padding == conv.dilation and conv.dilation[0] == conv.dilation[1]
+            and conv.in_channels >= 256 and conv.out_channels >= 256
+            and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0 and conv.padding_mode == "zeros")
+
+
 class _SynchronizedBatchNorm(_BatchNorm):
     def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True):
         super().__init__(num_features, eps=eps, momentum=momentum, affine=affine)
@@ -47,6 +55,27 @@ class _SynchronizedBatchNorm(_BatchNorm):
                 and input.dtype in (SF.torch.float32, SF.torch.bfloat16) and not input.is_contiguous()
                 and SF.pm_view_of(input) is not None and SF.pm_view_of(residual) is not None
                 and input.shape[1] % 4 == 0)
+
+    def can_fuse_conv(self, conv, input):
+        """Whether forward_conv_relu(conv, input) applies: a stride-1 3x3 convolution with padding = dilation, no
+        bias, 256 or more channels (multiples of 32) on both sides, a GPU tensor, and the mode set with
+        segk.config.set_feeder_conv."""
+        from ... import config
+        mode = config.feeder_conv()
+        if mode == "torch" or not (isinstance(input, SF.torch.Tensor) and input.is_cuda and input.dim() == 4):
+            return False
+        if not conv_is_hip_eligible(conv) or conv.out_channels != self.num_features:
+            return False
+        if input.dtype not in (SF.torch.float32, SF.torch.bfloat16):
+            return False
+        if mode == "auto":
+            return SF.pm_view_of(input) is not None and not input.is_contiguous()
+        return True
+
+    def forward_conv_relu(self, conv, input):
+        """relu(self(conv(input))) as one unit on the implicit-GEMM kernels (statistics from the convolution's
+        epilogue): a feeder bottleneck's conv2 -> bn2 -> relu."""
+        return SF.ConvBNReLUFunction.apply(input, conv.weight, self.weight, self.bias, conv, self)
 
     def __data_parallel_replicate__(self, ctx, copy_id):
         raise RuntimeError("this SynchronizedBatchNorm runs one process per GPU (torch.distributed); "

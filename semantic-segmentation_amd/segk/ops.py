@@ -126,16 +126,32 @@ def pm_to_nchw(src, N, H, W):
     return out
 
 
-def pack_weight(w, dtype, transpose=False, out=None):
-    """nn.Conv2d weight [Cout,Cin,R,R] fp32 -> [taps, rows, Ck] operand (see segk_pack_weight); `out` may be a
-    contiguous slice of a larger buffer of that shape."""
-    _dev(w)
-    if w.dtype != torch.float32:
-        raise ValueError("master weights are float32")
-    w = w.contiguous()
+def _weight_strides(w):
+    """(s_co, s_ci, s_tap) element strides of a dense [Cout, Cin, R, R] weight: contiguous or channels_last."""
     Cout, Cin, R, S = w.shape
     if R != S:
         raise ValueError("square kernels only")
+    st = w.stride()
+    if R == 1:
+        s_tap = 1
+    elif st[2] == R * st[3]:
+        s_tap = st[3]
+    else:
+        raise ValueError("weight of strides %s is not dense over its taps" % (st,))
+    return st[0], st[1], s_tap
+
+
+def pack_weight(w, dtype, transpose=False, out=None):
+    """nn.Conv2d weight [Cout,Cin,R,R] (fp32 or bf16; contiguous or channels_last) -> [taps, rows, Ck] operand
+    (see segk_pack_weight); `out` may be a contiguous slice of a larger buffer of that shape."""
+    _dev(w)
+    if w.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("weights are float32 or bfloat16")
+    Cout, Cin, R, S = w.shape
+    dense = w.is_contiguous() or w.is_contiguous(memory_format=torch.channels_last)
+    if not dense:
+        w = w.contiguous()
+    s_co, s_ci, s_tap = _weight_strides(w)
     rows, k = (Cin, Cout) if transpose else (Cout, Cin)
     shape = (R * R, rows, round_up(k, 32))
     if out is None:
@@ -143,7 +159,8 @@ def pack_weight(w, dtype, transpose=False, out=None):
     elif tuple(out.shape) != shape or out.dtype != dtype or not out.is_contiguous():
         raise ValueError("pack_weight destination must be a contiguous %s tensor of shape %s" % (dtype, shape))
     t0 = _hbm_start()
-    call("segk_pack_weight", _ptr(w), _ptr(out), _dt(out), Cout, Cin, R, 1 if transpose else 0, _stream())
+    call("segk_pack_weight_strided", _ptr(w), _dt(w), s_co, s_ci, s_tap, _ptr(out), _dt(out), Cout, Cin, R,
+         1 if transpose else 0, _stream())
     _hbm_stop("pack_weight", _nbytes(w, out), t0)
     return out
 
@@ -226,9 +243,10 @@ def default_splits(M, Cin, Cout, R, dtype):
     return max(1, min(target // tiles if tiles <= target else 1, 64, chunks // 8 if chunks >= 8 else 1))
 
 
-def conv_wgrad(x, dout, N, H, W, R, dil, Cout_true, Cin_true, splits=None):
-    """Weight gradient [Cout_true, Cin_true, R, R] fp32 from the forward input view x [M, Cin_pad] and the
-    output gradient view dout [M, Cout_pad] (padded channels must hold zeros)."""
+def conv_wgrad(x, dout, N, H, W, R, dil, Cout_true, Cin_true, splits=None, like=None):
+    """Weight gradient [Cout_true, Cin_true, R, R] from the forward input view x [M, Cin_pad] and the output gradient
+    view dout [M, Cout_pad] (padded channels must hold zeros): contiguous fp32, or with the dtype and strides of
+    the weight `like` (what autograd expects for a bf16 / channels_last parameter)."""
     _dev(x, dout)
     M = N * H * W
     in_ld, Cin = _pm(x)
@@ -243,11 +261,18 @@ def conv_wgrad(x, dout, N, H, W, R, dil, Cout_true, Cin_true, splits=None):
     a.inp, a.in_ld, a.Cin = x.data_ptr(), in_ld, Cin
     a.dout, a.dout_ld, a.Cout = dout.data_ptr(), do_ld, Cout
     a.R, a.dil, a.splits, a.slabs = R, dil, splits, slabs.data_ptr()
-    dw = torch.empty((Cout_true, Cin_true, R, R), dtype=torch.float32, device=x.device)
+    if like is None:
+        dw = torch.empty((Cout_true, Cin_true, R, R), dtype=torch.float32, device=x.device)
+    else:
+        if tuple(like.shape) != (Cout_true, Cin_true, R, R):
+            raise ValueError("gradient layout model has shape %s" % (tuple(like.shape),))
+        dw = torch.empty_strided(like.shape, like.stride(), dtype=like.dtype, device=x.device)
+    s_co, s_ci, s_tap = _weight_strides(dw)
     # the bracket holds the split-slab kernel AND the fixed-order sum of the slabs: the whole weight-gradient cost
     t0 = TIMER.start() if TIMER is not None else None
     call("segk_conv_wgrad", ctypes.byref(a), _stream())
-    call("segk_wgrad_finish", _ptr(slabs), splits, R, Cin, Cout, _ptr(dw), Cout_true, Cin_true, _stream())
+    call("segk_wgrad_finish_strided", _ptr(slabs), splits, R, Cin, Cout, _ptr(dw), _dt(dw), s_co, s_ci, s_tap,
+         Cout_true, Cin_true, _stream())
     if t0 is not None:
         TIMER.stop("conv_wgrad_kernel", 2.0 * M * Cout_true * Cin_true * R * R, t0)
     return dw

@@ -1,0 +1,117 @@
+"""The feeder's stride-1 3x3 bottleneck convolution + batch norm + ReLU as one unit on the implicit-GEMM kernels
+(/root/reference/newmodeling/backbone/resnet101_2.py:19-21 and Bottleneck.forward: conv2 -> bn2 -> relu) against the
+same three PyTorch operations in fp32 on the host, evaluated on the activation pattern the kernels produced."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from helpers import rel_err
+from oracle import gen
+
+pytestmark = pytest.mark.gpu
+SEED = 777
+
+
+def _reference(x, w, gamma, beta, gy, dil, mask):
+    x = x.clone().requires_grad_(True)
+    w = w.clone().requires_grad_(True)
+    gamma = gamma.clone().requires_grad_(True)
+    beta = beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(w.shape[0]), torch.ones(w.shape[0])
+    z = F.batch_norm(F.conv2d(x, w, None, 1, dil, dil), rm, rv, gamma, beta, True, 0.1, 1e-5)
+    y = z * mask
+    y.backward(gy)
+    return {"y": y.detach(), "dx": x.grad, "dw": w.grad, "dgamma": gamma.grad, "dbeta": beta.grad, "rm": rm, "rv": rv}
+
+
+def _inputs(C, n, h, w):
+    x = torch.from_numpy(gen.relu_normal(SEED, "fc/x", (n, C, h, w)))
+    wt = torch.from_numpy(gen.normal(SEED, "fc/w", (C, C, 3, 3), std=(2.0 / (9 * C)) ** 0.5))
+    gamma = torch.from_numpy(gen.uniform(SEED, "fc/g", (C,), 0.5, 1.5))
+    beta = torch.from_numpy(gen.normal(SEED, "fc/b", (C,), std=0.3))
+    gy = torch.from_numpy(gen.normal(SEED, "fc/gy", (n, C, h, w)))
+    return x, wt, gamma, beta, gy
+
+
+def _modules(C, dil, wt, gamma, beta, dev):
+    from segk.modeling.sync_batchnorm import SynchronizedBatchNorm2d
+    conv = nn.Conv2d(C, C, 3, padding=dil, dilation=dil, bias=False).to(dev)
+    bn = SynchronizedBatchNorm2d(C).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(wt)
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    return conv, bn
+
+
+@pytest.mark.parametrize("dil", [1, 2, 4])
+def test_unit_fp32_nchw(dil):
+    from segk import config
+    dev, C = "cuda", 256
+    x, wt, gamma, beta, gy = _inputs(C, 3, 9, 11)
+    conv, bn = _modules(C, dil, wt, gamma, beta, dev)
+    xd = x.to(dev).requires_grad_(True)
+    with config.feeder_conv_as("hip"):
+        assert bn.can_fuse_conv(conv, xd)
+        y = bn.forward_conv_relu(conv, xd)
+    with config.feeder_conv_as("auto"):
+        assert not bn.can_fuse_conv(conv, xd)             # NCHW activations stay on the PyTorch path by default
+        assert bn.can_fuse_conv(conv, xd.detach().contiguous(memory_format=torch.channels_last))
+    with config.feeder_conv_as("torch"):
+        assert not bn.can_fuse_conv(conv, xd.detach().contiguous(memory_format=torch.channels_last))
+    assert y.is_contiguous() and y.dtype == torch.float32
+    y.backward(gy.to(dev))
+    ref = _reference(x, wt, gamma, beta, gy, dil, (y.detach().cpu() > 0).float())
+    assert rel_err(y.detach().cpu().numpy(), ref["y"].numpy()) < 1e-4
+    assert rel_err(bn.running_mean.cpu().numpy(), ref["rm"].numpy()) < 1e-4
+    assert rel_err(bn.running_var.cpu().numpy(), ref["rv"].numpy()) < 1e-4
+    for k, g in (("dx", xd.grad), ("dw", conv.weight.grad), ("dgamma", bn.weight.grad), ("dbeta", bn.bias.grad)):
+        assert rel_err(g.cpu().numpy(), ref[k].numpy()) < 1e-3, k
+
+
+def test_unit_bf16_channels_last_weight_gradient_layout():
+    """The bench configuration: bf16 channels_last activations and a bf16 channels_last weight (held so by the
+    optimizer); the weight gradient comes back in that dtype and layout."""
+    dev, C, dil = "cuda", 512, 2
+    x, wt, gamma, beta, gy = _inputs(C, 3, 9, 11)
+    conv, bn = _modules(C, dil, wt, gamma, beta, dev)
+    conv = conv.to(memory_format=torch.channels_last)
+    conv.weight.data = conv.weight.data.to(torch.bfloat16)
+    xd = x.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert bn.can_fuse_conv(conv, xd)                     # mode "auto": pixel-major memory
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        y = bn.forward_conv_relu(conv, xd)
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(gy.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+    gw = conv.weight.grad
+    assert gw.dtype == torch.bfloat16 and gw.stride() == conv.weight.stride()
+    assert xd.grad.dtype == torch.bfloat16 and xd.grad.stride() == xd.stride()
+    ref = _reference(x.bfloat16().float(), wt.bfloat16().float(), gamma, beta, gy.bfloat16().float(), dil,
+                     (y.detach().float().cpu() > 0).float())
+    assert rel_err(y.detach().float().cpu().numpy(), ref["y"].numpy()) < 2e-2
+    for k, g in (("dx", xd.grad), ("dw", gw), ("dgamma", bn.weight.grad), ("dbeta", bn.bias.grad)):
+        assert rel_err(g.float().cpu().numpy(), ref[k].numpy()) < 2e-2, k
+
+
+def test_pack_weight_layouts_agree():
+    """segk_pack_weight_strided: fp32 OIHW, bf16 OIHW and bf16 channels_last sources give the same operand."""
+    from segk import ops
+    dev = "cuda"
+    w = torch.from_numpy(gen.normal(SEED, "pw/w", (70, 100, 3, 3))).to(dev)
+    wb = w.to(torch.bfloat16)
+    for transpose in (False, True):
+        a = ops.pack_weight(wb.float(), torch.bfloat16, transpose)
+        b = ops.pack_weight(wb, torch.bfloat16, transpose)
+        c = ops.pack_weight(wb.contiguous(memory_format=torch.channels_last), torch.bfloat16, transpose)
+        assert torch.equal(a, b) and torch.equal(a, c)
+        rows, k = (100, 70) if transpose else (70, 100)
+        assert tuple(a.shape) == (9, rows, ops.round_up(k, 32))
+        src = wb.float().flip(2, 3).permute(2, 3, 1, 0) if transpose else wb.float().permute(2, 3, 0, 1)
+        want = torch.zeros(a.shape, device=dev)
+        want[:, :, :k] = src.reshape(9, rows, k)
+        assert torch.equal(a.float(), want)
+    w1 = torch.from_numpy(gen.normal(SEED, "pw/w1", (48, 256, 1, 1))).to(dev)
+    p1 = ops.pack_weight(w1, torch.float32)
+    assert torch.equal(p1[0], w1.reshape(48, 256))

@@ -77,7 +77,7 @@ def run_with_capture(fn):
     SF.CAPTURE = []
     try:
         out = fn()
-        masks = [SF.nchw_view_of(v, *g) > 0 for v, g in SF.CAPTURE]
+        masks = [(SF.nchw_view_of(v, *g) if g is not None else v) > 0 for v, g in SF.CAPTURE]
     finally:
         SF.CAPTURE = None
     return out, masks
@@ -320,19 +320,22 @@ def test_fullsize_D_bf16(impl):
 
 
 # --------------------------------------------------------------- whole model ----
-def _first_step_grads(impl, device):
+def _first_step_grads(impl, device, channels_last_feeder=False):
     """Loss and every parameter gradient of the first training step of the e2e case."""
     from oracle import gen
     model = cases._load(impl.DeepLab(), cases.SEED, "e2e", device)
     cases._zero_dropout(model)
     model.train()
     image = torch.from_numpy(gen.normal(cases.SEED, "e2e/img0", (4, 3, 65, 65)) * cases._gain(4)).to(device)
+    if channels_last_feeder:   # pixel-major activations: every fused batch-norm form of the feeder applies
+        model.backbone = model.backbone.to(memory_format=torch.channels_last)
+        image = image.contiguous(memory_format=torch.channels_last)
     target = torch.from_numpy(gen.labels(cases.SEED, "e2e/lab0", (4, 65, 65), 21, border=2)).to(device)
     loss = impl.ce_loss(model(image), target, None)
     loss.backward()
     out = {"loss": loss.detach().float().cpu().numpy().reshape(1)}
     for n, p in model.named_parameters():
-        out["d/" + n] = p.grad.detach().float().cpu().numpy()
+        out["d/" + n] = p.grad.detach().float().contiguous().cpu().numpy()
     return out
 
 
@@ -350,6 +353,30 @@ def test_e2e_first_step_gradients_all_parameters(impl):
     # (measured 0.3e-2 .. 2.5e-2 from run to run; a wrong gradient from the head would show as O(1))
     worst = max(rel_l2(got[k], v) for k, v in want.items() if k.startswith("d/backbone."))
     assert worst < 1e-1, worst
+
+
+def test_e2e_first_step_gradients_hip_feeder_convs(impl_sync):
+    """The feeder's 25 stride-1 3x3 bottleneck convolutions of layers 3 and 4 on the implicit-GEMM kernels (statistics
+    from the convolution epilogue), HIP batch norm in every feeder layer.  Every ReLU of the network reports its
+    activation pattern and the oracle (its feeder convolutions on MIOpen) is evaluated on that pattern: loss and ALL
+    parameter gradients, feeder included, at the head's gates.  Only the stem (conv1 / bn1, in front of the max
+    pooling, whose arg-max choice is a second non-smooth operation that is not pattern-matched) is held by L2."""
+    from segk import config
+    with config.feeder_conv_as("auto"):
+        got, masks = run_with_capture(lambda: _first_step_grads(impl_sync, "cuda", channels_last_feeder=True))
+    assert len(masks) == 1 + 3 * 33 + 9, len(masks)
+    oracle = oracle_impl("cuda")
+    oracle.DeepLab = lambda: head_ref.RefDeepLab("resnet", 16, 21, nn.BatchNorm2d, mask_feeder_relus=True)
+    with head_ref.use_relu_masks(masks):
+        want = _first_step_grads(oracle, "cuda")
+    stem = ("d/backbone.conv1.weight", "d/backbone.bn1.weight", "d/backbone.bn1.bias")
+    # the oracle's convolutions run on MIOpen here (about 2e-4 from exact fp32 in the 2048-channel layers) and the
+    # deepest batch norms see 100 values per channel: 2e-3 on gradients at this tiny size, as in test_e2e_damm_fp32
+    assert_dicts_close(got, {k: v for k, v in want.items() if k not in stem}, FWD, 2e-3)
+    # (the stem's batch-norm bias gradient is a sum over 4 x 33 x 33 positions per channel that cancels almost
+    # completely, measured 0.28 in L2 between the channels_last MIOpen kernels here and the NCHW ones of the oracle)
+    for k in stem:
+        assert rel_l2(got[k], want[k]) < (5e-1 if k.endswith("bn1.bias") else 1e-1), (k, rel_l2(got[k], want[k]))
 
 
 def _e2e_check(got, want):
