@@ -78,6 +78,11 @@ typedef struct {
   int Ck;          /* contracted channels, multiple of 32, <= in_ld */
   int R;           /* 1 or 3 (square kernel, stride 1, padding = dil*(R-1)/2: output size = input size) */
   int dil;
+  /* Elements between the rows (output channels) and between the taps of `w`; 0 = the packed layout above
+   * (Ck and Cout*Ck).  A channels_last nn.Conv2d weight [Cout][R*R][Cin] of the operand dtype is used in place with
+   * (R*R*Cin, Cin) when Cin is a multiple of 32: no packing pass for the forward convolution. */
+  long long w_row_stride;
+  long long w_tap_stride;
 } segk_conv_seg;
 
 typedef struct {
@@ -121,6 +126,8 @@ typedef struct {
   int R, dil;
   int splits;      /* >= 1: the pixel range is cut into `splits` parts summed later in fixed order */
   float* slabs;    /* [splits][R*R][Cin][Cout] fp32 partial weight gradients */
+  int tile;        /* 0: the library chooses the workgroup tile; 128 / 256: that square tile (256 needs Cout % 256 == 0
+                      and Cin >= 256).  Callers that size `splits` for a given tile pass it here. */
 } segk_wgrad_args;
 
 /* Weight gradient of nn.Conv2d (autograd of modeling/aspp.py:18, modeling/decoder.py:172,178). */

@@ -1094,7 +1094,7 @@ static int set_lds(K kernel, int bytes, const char* name, LdsConfigured& done) {
 
 // Launch the weight-gradient kernel; the 256 x 256 tile is used when the output channels fill it exactly.
 template <typename T>
-static int launch_wgrad(WgradDev& d, int batch, hipStream_t st, const char* name) {
+static int launch_wgrad(WgradDev& d, int batch, hipStream_t st, const char* name, int tile = 0) {
   static const char* force = experiment("SEGK_WGRAD_TILE");  // experiments: "small" (register-staged 128 tile) / "big" / "dma"
   // The 256 x 256 tile when the output channels fill it exactly and the last input-channel tile is more than half
   // full (320 input channels would run a second tile that is a quarter full); otherwise the 128 x 128 tile, for
@@ -1103,6 +1103,8 @@ static int launch_wgrad(WgradDev& d, int batch, hipStream_t st, const char* name
   if (force && force[0] == 's') big = false;
   if (force && force[0] == 'b') big = d.Cin >= 256 && d.Cout % 256 == 0;
   if (force && force[0] == 'd') big = false;   // "dma": the 128 x 128 LDS-DMA tile everywhere (bf16)
+  if (tile == 128) big = false;
+  if (tile == 256) big = d.Cin >= 256 && d.Cout % 256 == 0;
   if (sizeof(T) == 2 && !big && !(force && force[0] == 's')) {
     d.co_tiles = ceil_div(d.Cout, TILE);
     d.ci_tiles = ceil_div(d.Cin, TILE);
@@ -1471,6 +1473,11 @@ static int conv_check(const segk_conv_args* a) {
     SEGK_REQUIRE(g.Ck > 0 && g.Ck % 32 == 0 && g.Ck <= g.in_ld, "conv: segment %d Ck=%d must be a multiple of 32 and <= ld=%d",
                  s, g.Ck, g.in_ld);
     SEGK_REQUIRE(((long long)g.in_ld * es) % 16 == 0, "conv: segment %d row stride not a multiple of 16 bytes", s);
+    SEGK_REQUIRE(g.w_row_stride >= 0 && g.w_tap_stride >= 0 && (g.w_row_stride * es) % 16 == 0 &&
+                     (g.w_tap_stride * es) % 16 == 0 && g.w_row_stride * es < 2147483647LL / 256 &&
+                     (g.w_row_stride == 0 || g.w_row_stride >= g.Ck),
+                 "conv: segment %d weight strides (%lld, %lld) must be non-negative multiples of 16 bytes, rows >= Ck",
+                 s, g.w_row_stride, g.w_tap_stride);
   }
   return SEGK_OK;
 }
@@ -1489,10 +1496,10 @@ static bool fill_dev(const segk_conv_args* a, ConvDev& d) {
     d.seg[s].w = (const char*)g.w;
     d.seg[s].in_ld_b = (long long)g.in_ld * es;
     d.seg[s].ck_b = g.Ck * es;
-    d.seg[s].w_ld_b = g.Ck * es;
+    d.seg[s].w_ld_b = (int)((g.w_row_stride > 0 ? g.w_row_stride : (long long)g.Ck) * es);
     d.seg[s].in_batch_b = 0;
     d.seg[s].w_batch_b = (long long)a->w_batch * es;
-    d.seg[s].w_tap_b = (long long)a->Cout * g.Ck * es;
+    d.seg[s].w_tap_b = (g.w_tap_stride > 0 ? g.w_tap_stride : (long long)a->Cout * g.Ck) * es;
     d.seg[s].R = g.R;
     d.seg[s].dil = g.dil;
     if (s < a->nseg && (d.seg[s].ck_b % 128) != 0) wide = false;
@@ -1628,7 +1635,9 @@ extern "C" int segk_conv_wgrad(const segk_wgrad_args* a, segk_stream_t stream) {
   d.slabs = a->slabs;
   d.in_batch_b = 0; d.dout_batch_b = 0;
   hipStream_t st = (hipStream_t)stream;
-  int rc = a->dtype == SEGK_BF16 ? launch_wgrad<bf16_t>(d, 1, st, "conv_wgrad") : launch_wgrad<float>(d, 1, st, "conv_wgrad");
+  SEGK_REQUIRE(a->tile == 0 || a->tile == 128 || a->tile == 256, "wgrad: tile=%d (0, 128 or 256)", a->tile);
+  int rc = a->dtype == SEGK_BF16 ? launch_wgrad<bf16_t>(d, 1, st, "conv_wgrad", a->tile)
+                                 : launch_wgrad<float>(d, 1, st, "conv_wgrad", a->tile);
   if (rc != SEGK_OK) return rc;
   SEGK_CHECK_LAUNCH("conv_wgrad");
   return SEGK_OK;

@@ -65,43 +65,47 @@ __global__ __launch_bounds__(256) void pm_to_nchw_kernel(const TS* __restrict__ 
 // dst[tapd][row][k]: transpose == 0: row = co, k = ci, tapd = tap; transpose == 1: row = ci, k = co,
 // tapd = taps-1-tap.  k runs to Ck (multiple of 32); the tail is zero.
 // The source is any dense layout of the [Cout][Cin][taps] weight given by three element strides (OIHW: s_tap = 1,
-// channels_last: s_ci = 1).  One block moves a 32(co) x 32(ci) patch of every tap through LDS: it reads in the
-// source's own order (runs of 32*taps or 32 elements) and writes runs of 32 along k.
-template <typename TS, typename TD, int TAPS>
+// channels_last: s_ci = 1).  One block moves a PCO(co) x 32(ci) patch of TPB taps through LDS: it reads in the
+// source's own order and writes runs along k.  TPB = all taps for a tap-fastest source (runs of 32*taps elements
+// per output channel), 1 for a channel-fastest source (blockIdx.z = tap; runs of 32 elements).
+template <typename TS, typename TD, int TPB, int PCO>
 __global__ __launch_bounds__(256) void pack_weight_kernel(const TS* __restrict__ w, long long s_co, long long s_ci,
                                                            long long s_tap, TD* __restrict__ dst, int Cout, int Cin,
-                                                           int rows, int Ck, int transpose) {
-  __shared__ float tile[TAPS][32][33];
-  const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
-  constexpr int PATCH = 32 * 32 * TAPS;
-  const bool tap_fastest = s_tap == 1;
+                                                           int taps, int rows, int Ck, int transpose) {
+  __shared__ float tile[TPB][PCO][33];
+  const int co0 = blockIdx.x * PCO, ci0 = blockIdx.y * 32;
+  const int tap0 = TPB == 1 ? blockIdx.z : 0;
+  constexpr int PATCH = PCO * 32 * TPB;
   for (int i = threadIdx.x; i < PATCH; i += 256) {
     int co_l, ci_l, tap;
-    if (tap_fastest) {           // (co, ci, tap): tap then ci contiguous in the source
-      co_l = i / (32 * TAPS);
-      const int rem = i - co_l * (32 * TAPS);
-      ci_l = rem / TAPS;
-      tap = rem - ci_l * TAPS;
-    } else {                     // (co, tap, ci): ci contiguous in the source
-      co_l = i / (32 * TAPS);
-      const int rem = i - co_l * (32 * TAPS);
-      tap = rem >> 5;
-      ci_l = rem & 31;
+    if (TPB > 1) {               // (co, ci, tap): tap then ci contiguous in the source
+      co_l = i / (32 * TPB);
+      const int rem = i - co_l * (32 * TPB);
+      ci_l = rem / TPB;
+      tap = rem - ci_l * TPB;
+    } else {                     // (co, ci): ci contiguous in the source
+      co_l = i >> 5;
+      ci_l = i & 31;
+      tap = 0;
     }
     const int co = co0 + co_l, ci = ci0 + ci_l;
     float v = 0.f;
-    if (co < Cout && ci < Cin) v = Elem<TS>::load(w + co * s_co + ci * s_ci + tap * s_tap);
+    if (co < Cout && ci < Cin) v = Elem<TS>::load(w + co * s_co + ci * s_ci + (tap0 + tap) * s_tap);
     tile[tap][co_l][ci_l] = v;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < PATCH; i += 256) {
-    const int k_l = i & 31, r_l = (i >> 5) & 31, tap = i >> 10;
-    // transpose == 0: row = co, k = ci;  transpose == 1: row = ci, k = co, taps reversed
-    const int row = (transpose ? ci0 : co0) + r_l, k = (transpose ? co0 : ci0) + k_l;
-    if (row < rows && k < Ck) {
-      const int tapd = transpose ? TAPS - 1 - tap : tap;
-      const float v = transpose ? tile[tap][k_l][r_l] : tile[tap][r_l][k_l];
-      Elem<TD>::store(dst + ((size_t)tapd * rows + row) * Ck + k, v);
+  if (!transpose) {              // rows = co, k = ci: runs of 32 along ci
+    for (int i = threadIdx.x; i < PATCH; i += 256) {
+      const int k_l = i & 31, r_l = (i >> 5) % PCO, tap = i / (32 * PCO);
+      const int row = co0 + r_l, k = ci0 + k_l;
+      if (row < rows && k < Ck) Elem<TD>::store(dst + ((size_t)(tap0 + tap) * rows + row) * Ck + k, tile[tap][r_l][k_l]);
+    }
+  } else {                       // rows = ci, k = co, taps reversed: runs of PCO along co
+    for (int i = threadIdx.x; i < PATCH; i += 256) {
+      const int k_l = i % PCO, r_l = (i / PCO) & 31, tap = i / (32 * PCO);
+      const int row = ci0 + r_l, k = co0 + k_l;
+      if (row < rows && k < Ck)
+        Elem<TD>::store(dst + ((size_t)(taps - 1 - tap0 - tap) * rows + row) * Ck + k, tile[tap][k_l][r_l]);
     }
   }
 }
@@ -177,11 +181,14 @@ template <typename TS, typename TD>
 static void launch_pack(const void* w, long long s_co, long long s_ci, long long s_tap, void* dst, int Cout, int Cin,
                         int taps, int rows, int Ck, int transpose, hipStream_t st) {
   // patches cover co up to Cout (or up to Ck when co is the padded k index) and ci likewise
-  dim3 grid(ceil_div(transpose ? Ck : Cout, 32), ceil_div(transpose ? Cin : Ck, 32));
-  if (taps == 9)
-    pack_weight_kernel<TS, TD, 9><<<grid, 256, 0, st>>>((const TS*)w, s_co, s_ci, s_tap, (TD*)dst, Cout, Cin, rows, Ck, transpose);
-  else
-    pack_weight_kernel<TS, TD, 1><<<grid, 256, 0, st>>>((const TS*)w, s_co, s_ci, s_tap, (TD*)dst, Cout, Cin, rows, Ck, transpose);
+  const int co_ext = transpose ? Ck : Cout, ci_ext = transpose ? Cin : Ck;
+  if (taps == 9 && s_tap == 1) {   // OIHW: all nine taps of a 16 x 32 patch per block
+    dim3 grid(ceil_div(co_ext, 16), ceil_div(ci_ext, 32));
+    pack_weight_kernel<TS, TD, 9, 16><<<grid, 256, 0, st>>>((const TS*)w, s_co, s_ci, s_tap, (TD*)dst, Cout, Cin, taps, rows, Ck, transpose);
+  } else {                         // channels_last, or a 1x1 kernel: one tap of a 32 x 32 patch per block
+    dim3 grid(ceil_div(co_ext, 32), ceil_div(ci_ext, 32), taps);
+    pack_weight_kernel<TS, TD, 1, 32><<<grid, 256, 0, st>>>((const TS*)w, s_co, s_ci, s_tap, (TD*)dst, Cout, Cin, taps, rows, Ck, transpose);
+  }
 }
 
 extern "C" int segk_pack_weight_strided(const void* w, int w_dtype, long long s_co, long long s_ci, long long s_tap,

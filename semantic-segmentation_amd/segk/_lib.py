@@ -18,7 +18,8 @@ c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, 
 
 
 class ConvSeg(ctypes.Structure):
-    _fields_ = [("inp", c_void_p), ("w", c_void_p), ("in_ld", c_int), ("Ck", c_int), ("R", c_int), ("dil", c_int)]
+    _fields_ = [("inp", c_void_p), ("w", c_void_p), ("in_ld", c_int), ("Ck", c_int), ("R", c_int), ("dil", c_int),
+                ("w_row_stride", c_ll), ("w_tap_stride", c_ll)]
 
 
 class ConvArgs(ctypes.Structure):
@@ -31,7 +32,7 @@ class ConvArgs(ctypes.Structure):
 class WgradArgs(ctypes.Structure):
     _fields_ = [("N", c_int), ("H", c_int), ("W", c_int), ("dtype", c_int), ("inp", c_void_p), ("in_ld", c_int),
                 ("Cin", c_int), ("dout", c_void_p), ("dout_ld", c_int), ("Cout", c_int), ("R", c_int),
-                ("dil", c_int), ("splits", c_int), ("slabs", c_void_p)]
+                ("dil", c_int), ("splits", c_int), ("slabs", c_void_p), ("tile", c_int)]
 
 
 class GemmTerm(ctypes.Structure):

@@ -640,8 +640,10 @@ class ConvBNReLUFunction(torch.autograd.Function):
         M = N * H * W
         spec = _BNSpec(bn)
         raw = torch.empty((M, Cout), dtype=cd, device=x.device)
-        stats = ops.conv_fwd([(xv, ops.pack_weight(weight.detach(), cd), R, dil)], N, H, W, Cout, raw,
-                             want_stats=spec.training, true_ck=[Cin])
+        w_op = weight.detach()
+        if w_op.dtype != cd or not ops.weight_usable_in_place(w_op, R, Cout):   # a channels_last bf16 weight is read as it is
+            w_op = ops.pack_weight(w_op, cd)
+        stats = ops.conv_fwd([(xv, w_op, R, dil)], N, H, W, Cout, raw, want_stats=spec.training, true_ck=[Cin])
         y = torch.empty((N, Cout, H, W), dtype=cd, device=x.device, memory_format=torch.channels_last)
         rec = unit_finish(xv, raw, stats, weight, R, dil, (N, H, W), spec, gamma, beta, pm_view_of(y), relu=True)
         ctx.rec, ctx.x = rec, x

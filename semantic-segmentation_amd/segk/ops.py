@@ -166,13 +166,26 @@ def pack_weight(w, dtype, transpose=False, out=None):
 
 
 # -------------------------------------------------------------------- conv ----
+def weight_usable_in_place(w, R, Cout):
+    """An nn.Conv2d weight the forward convolution can read without packing: [Cout, Cin, R, R], dense channels_last
+    (input channels contiguous), Cin a multiple of 32."""
+    if w.dim() != 4 or w.shape[0] != Cout or w.shape[2] != R or w.shape[3] != R or w.shape[1] % 32 != 0:
+        return False
+    Cin = w.shape[1]
+    if R == 1:
+        return w.stride(1) == 1 and w.stride(0) == Cin
+    return w.stride(1) == 1 and w.stride(3) == Cin and w.stride(2) == R * Cin and w.stride(0) == R * R * Cin
+
+
 def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=False, true_ck=None, batch=1,
              dil_step=0, out_batch=0):
-    """segs: list of (in_view [M, >=Ck], packed_w [taps, Cout, Ck], R, dil).  Writes `out` ([M, Cout'] view,
-    Cout' >= Cout rounded up to 4).  Returns the [rows, 2, Cout] statistic partials when want_stats.
+    """segs: list of (in_view [M, >=Ck], packed_w [taps, Cout, Ck], R, dil); instead of a packed operand a segment
+    may carry the nn.Conv2d weight itself when it is channels_last [Cout, Cin, R, R] of the operand dtype with Cin a
+    multiple of 32 (used in place).  Writes `out` ([M, Cout'] view, Cout' >= Cout rounded up to 4).  Returns the [rows, 2, Cout] statistic partials when want_stats.
     true_ck: un-padded contracted channel counts per segment (only used for FLOP accounting)."""
     M = N * H * W
-    timer_ck = true_ck if true_ck is not None else [w.shape[-1] for _, w, _, _ in segs]
+    timer_ck = true_ck if true_ck is not None else [(w.shape[1] if w.dim() == 4 and batch <= 1 else w.shape[-1])
+                                                    for _, w, _, _ in segs]
     a = ConvArgs()
     a.N, a.H, a.W, a.Cout, a.nseg = N, H, W, Cout, len(segs)
     if not 1 <= len(segs) <= _lib.MAX_SEG:
@@ -183,7 +196,10 @@ def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=Fals
         ld, _ = _pm(x)
         if x.shape[0] != M:
             raise ValueError("segment %d has %d pixels, expected %d" % (i, x.shape[0], M))
-        if batch > 1:
+        in_place = batch <= 1 and weight_usable_in_place(w, R, Cout)
+        if in_place:
+            pass
+        elif batch > 1:
             if w.dim() != 4 or not w.is_contiguous() or w.shape[0] != batch or w.shape[1] != R * R or w.shape[2] != Cout:
                 raise ValueError("segment %d: batched packed weight shape %s does not match batch=%d taps=%d Cout=%d"
                                  % (i, tuple(w.shape), batch, R * R, Cout))
@@ -193,7 +209,8 @@ def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=Fals
         if x.dtype != w.dtype or (dt is not None and x.dtype != dt):
             raise ValueError("all conv operands share one dtype")
         dt = x.dtype
-        Ck = w.shape[-1]
+        Ck = w.shape[1] if in_place else w.shape[-1]
+        a.seg[i].w_row_stride, a.seg[i].w_tap_stride = (w.stride(0), (w.stride(3) if R > 1 else Ck)) if in_place else (0, 0)
         if x.shape[1] < Ck and ld < Ck:
             raise ValueError("segment %d: activation row has %d elements, weight contracts %d" % (i, ld, Ck))
         a.seg[i].inp, a.seg[i].w = x.data_ptr(), w.data_ptr()
@@ -230,17 +247,39 @@ def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=Fals
     return stats
 
 
-def default_splits(M, Cin, Cout, R, dtype):
-    """Parts of the pixel range so that the launch fills the chip: the 256x256-tile kernel (Cout a multiple of 256,
-    Cin at least 256 with a last tile more than half full) runs one workgroup per CU, the 128x128 one two (fp32) or
-    three (bf16, LDS-DMA)."""
-    big = Cin >= 256 and Cout % 256 == 0 and (Cin % 256 == 0 or Cin % 256 > 128)
-    t = 256 if big else 128
-    tiles = ((Cin + t - 1) // t) * ((Cout + t - 1) // t) * R * R
-    target = 256 if big else (768 if dtype == torch.bfloat16 else 1024)
+def wgrad_plan(M, Cin, Cout, R, dtype):
+    """-> (tile, splits) of a weight gradient: parts of the pixel range so that the launch fills the chip.  The
+    256 x 256-tile kernel (Cout a multiple of 256, Cin at least 256 with a last tile more than half full) runs one
+    workgroup per CU, the 128 x 128 one two (fp32) or three (bf16, LDS-DMA).  Every part writes a whole fp32 copy of
+    the gradient, so with few pixels per part (the 33 x 33 maps of the feeder's layers 3 and 4) the slabs and the
+    pass that sums them outweigh the multiplication: there the small tile is used (four times the workgroups per
+    part) with only as many parts as keep the slabs within SLAB_BUDGET, but at least one workgroup per CU."""
     bp = 64 if dtype == torch.bfloat16 else 32
     chunks = max(1, (M + bp - 1) // bp)
-    return max(1, min(target // tiles if tiles <= target else 1, 64, chunks // 8 if chunks >= 8 else 1))
+    big = Cin >= 256 and Cout % 256 == 0 and (Cin % 256 == 0 or Cin % 256 > 128)
+
+    def parts(t, target):
+        tiles = ((Cin + t - 1) // t) * ((Cout + t - 1) // t) * R * R
+        # narrow layers (the 48- and 21-channel 1x1 convolutions) have one or two tiles and tiny slabs: many parts
+        cap = 4 * SPLIT_CAP if 4 * SPLIT_CAP * R * R * Cin * Cout * 4 <= SLAB_BUDGET else SPLIT_CAP
+        return max(1, min(target // tiles if tiles <= target else 1, cap, chunks // 8 if chunks >= 8 else 1))
+    small_target = 768 if dtype == torch.bfloat16 else 1024
+    if big:
+        sp = parts(256, 256)
+        slab = R * R * Cin * Cout * 4
+        if dtype == torch.bfloat16 and sp * slab > SLAB_BUDGET and chunks // sp < 64:
+            fill, most = parts(128, 256), parts(128, small_target)
+            return 128, max(fill, min(most, SLAB_BUDGET // slab))
+        return 256, sp
+    return 128, parts(128, small_target)
+
+
+SPLIT_CAP = 64
+SLAB_BUDGET = 32 << 20
+
+
+def default_splits(M, Cin, Cout, R, dtype):
+    return wgrad_plan(M, Cin, Cout, R, dtype)[1]
 
 
 def conv_wgrad(x, dout, N, H, W, R, dil, Cout_true, Cin_true, splits=None, like=None):
@@ -253,14 +292,15 @@ def conv_wgrad(x, dout, N, H, W, R, dil, Cout_true, Cin_true, splits=None, like=
     do_ld, Cout = _pm(dout)
     if x.shape[0] != M or dout.shape[0] != M or x.dtype != dout.dtype:
         raise ValueError("wgrad operands disagree: %s %s M=%d" % (tuple(x.shape), tuple(dout.shape), M))
+    tile = 0
     if splits is None:
-        splits = default_splits(M, Cin, Cout, R, x.dtype)
+        tile, splits = wgrad_plan(M, Cin, Cout, R, x.dtype)
     slabs = torch.empty((splits, R * R, Cin, Cout), dtype=torch.float32, device=x.device)
     a = WgradArgs()
     a.N, a.H, a.W, a.dtype = N, H, W, _dt(x)
     a.inp, a.in_ld, a.Cin = x.data_ptr(), in_ld, Cin
     a.dout, a.dout_ld, a.Cout = dout.data_ptr(), do_ld, Cout
-    a.R, a.dil, a.splits, a.slabs = R, dil, splits, slabs.data_ptr()
+    a.R, a.dil, a.splits, a.slabs, a.tile = R, dil, splits, slabs.data_ptr(), tile
     if like is None:
         dw = torch.empty((Cout_true, Cin_true, R, R), dtype=torch.float32, device=x.device)
     else:

@@ -36,7 +36,9 @@ def main():
         w = torch.randn((C, C, 3, 3), device=dev) * 0.05
         wp, wpt = ops.pack_weight(w, dt), ops.pack_weight(w, dt, transpose=True)
         out = torch.empty((M, C), dtype=dt, device=dev)
-        t_f = timeit(lambda: ops.conv_fwd([(x, wp, 3, dil)], n, H, H, C, out, want_stats=True))
+        wcl = w.to(dt).contiguous(memory_format=torch.channels_last)
+        t_p = timeit(lambda: ops.pack_weight(wcl, dt, transpose=True))
+        t_f = timeit(lambda: ops.conv_fwd([(x, wcl if C % 32 == 0 else wp, 3, dil)], n, H, H, C, out, want_stats=True))
         t_d = timeit(lambda: ops.conv_fwd([(dy, wpt, 3, dil)], n, H, H, C, out))
         t_w = timeit(lambda: ops.conv_wgrad(x, dy, n, H, H, 3, dil, C, C))
         x4 = x.reshape(n, H, H, C).permute(0, 3, 1, 2).requires_grad_(True)
@@ -50,8 +52,8 @@ def main():
             F.conv2d(x4, w4, padding=dil, dilation=dil).backward(g4)
         t_tb = timeit(both) - t_tf
         t_st = timeit(lambda: ops.bn_local_sums(out, 0))
-        print("%-14s M=%6d C=%4d | segk fwd+stats %6.1f dgrad %6.1f wgrad %6.1f us | torch fwd %6.1f (+stats kernel %5.1f) "
-              "bwd %6.1f us" % (name, M, C, t_f, t_d, t_w, t_tf, t_st, t_tb))
+        print("%-14s M=%6d C=%4d | segk pack^T %5.1f fwd+stats %6.1f dgrad %6.1f wgrad %6.1f us | torch fwd %6.1f (+stats kernel %5.1f) "
+              "bwd %6.1f us" % (name, M, C, t_p, t_f, t_d, t_w, t_tf, t_st, t_tb))
 
 
 if __name__ == "__main__":
