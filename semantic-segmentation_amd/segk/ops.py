@@ -260,9 +260,7 @@ def wgrad_plan(M, Cin, Cout, R, dtype):
 
     def parts(t, target):
         tiles = ((Cin + t - 1) // t) * ((Cout + t - 1) // t) * R * R
-        # narrow layers (the 48- and 21-channel 1x1 convolutions) have one or two tiles and tiny slabs: many parts
-        cap = 4 * SPLIT_CAP if 4 * SPLIT_CAP * R * R * Cin * Cout * 4 <= SLAB_BUDGET else SPLIT_CAP
-        return max(1, min(target // tiles if tiles <= target else 1, cap, chunks // 8 if chunks >= 8 else 1))
+        return max(1, min(target // tiles if tiles <= target else 1, SPLIT_CAP, chunks // 8 if chunks >= 8 else 1))
     small_target = 768 if dtype == torch.bfloat16 else 1024
     if big:
         sp = parts(256, 256)
