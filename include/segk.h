@@ -244,36 +244,6 @@ int segk_bn_reduce_coeffs(const double* partials, int rows, int C, double count,
                           const float* beta, float eps, float momentum, int legacy_clamp, float* running_mean,
                           float* running_var, float* mean, float* inv_std, float* scale, float* shift, double* sums,
                           segk_stream_t stream);
-/* segk_bn_stats / segk_bn_bwd_stats followed by segk_bn_reduce (and segk_bn_coeffs) inside ONE launch, pixel-major
- * layout: the workgroup that finishes last among those of a channel slab sums the slab's partial rows in
- * segk_bn_reduce's fixed order (bit-identical results) and writes `sums` ([2C+1] fp64: what ranks all-reduce,
- * batchnorm.py:101-102), `sums_f32` ([2C], the backward pass's d(beta), d(gamma)) and, when `mean` is given, the
- * coefficients and running statistics of segk_bn_coeffs (batchnorm.py:113-125, :73).  `counters`:
- * segk_bn_tail_counters(C) unsigned ints that the caller zeroes ONCE; every launch leaves them zero, so launches
- * ordered on one stream share them (launches that overlap need their own). */
-typedef struct {
-  unsigned int* counters;
-  double count;            /* elements per channel behind the partial rows (written to sums[2C]) */
-  double* sums;            /* NULL or [2C+1] */
-  float* sums_f32;         /* NULL or [2C] */
-  const float* gamma;      /* coefficient part, used when mean != NULL; gamma/beta NULL = 1/0 */
-  const float* beta;
-  float eps, momentum;
-  int legacy_clamp;
-  float* running_mean;     /* may be NULL */
-  float* running_var;
-  float* mean;
-  float* inv_std;
-  float* scale;
-  float* shift;
-} segk_bn_tail;
-int segk_bn_tail_counters(int C);
-int segk_bn_stats_tail(const void* x, int dtype, int N, int C, int HW, int ld, double* partials,
-                       const segk_bn_tail* tail, segk_stream_t stream);
-int segk_bn_bwd_stats_tail(const void* dz, int dz_dtype, int dz_ld, const void* x, int x_dtype, int x_ld, int N, int C,
-                           int HW, const float* mean, const float* inv_std, const float* scale, const float* shift,
-                           int relu, const uint8_t* mask, float mask_scale, const void* act, int act_ld,
-                           double* partials, const segk_bn_tail* tail, segk_stream_t stream);
 /* Evaluation mode (batchnorm.py:50-53 with training False): coefficients from running statistics. */
 int segk_bn_coeffs_eval(const float* running_mean, const float* running_var, const float* gamma,
                         const float* beta, float eps, float* mean, float* inv_std, float* scale, float* shift,

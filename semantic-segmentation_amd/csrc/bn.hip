@@ -142,123 +142,9 @@ __device__ __forceinline__ void block_reduce_pm(ACC (&a)[VEC], ACC (&b)[VEC], co
   }
 }
 
-// global sums of one channel -> mean, inv_std, running statistics, scale, shift
-__device__ __forceinline__ void bn_coeff_one(double s, double q, double cnt, int c, const float* gamma, const float* beta,
-                                             float eps, float momentum, int legacy_clamp, float* running_mean,
-                                             float* running_var, float* mean, float* inv_std, float* scale,
-                                             float* shift) {
-  // sums are fp64 end to end (exact squares, fp64 accumulation), so this cancellation is harmless
-  const double mu = s / cnt;
-  double sumvar = q - s * mu;
-  if (sumvar < 0.0) sumvar = 0.0;
-  const double var_b = sumvar / cnt;
-  const double var_u = sumvar / (cnt - 1.0);
-  const double is = legacy_clamp ? 1.0 / sqrt(var_b > (double)eps ? var_b : (double)eps) : 1.0 / sqrt(var_b + (double)eps);
-  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
-  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)var_u;
-  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-  const float muf = (float)mu, isf = (float)is;
-  mean[c] = muf;
-  inv_std[c] = isf;
-  const float sc = g * isf;
-  scale[c] = sc;
-  shift[c] = b - muf * sc;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Tail of the pixel-major statistics kernels: the workgroup that finishes LAST among those of one channel slab sums
-// the slab's partial rows (same fixed order as bn_reduce_kernel: rows phase, phase+16, ... per column, then the 16
-// phase sums in order) and writes the sums and / or the batch-norm coefficients, which saves the separate reduce
-// launch of every layer.  Hand-off between workgroups: every wavefront drains its stores, the workgroup's barrier,
-// one agent-scope release, a ticket from an integer counter; the workgroup that draws the last ticket makes one
-// agent-scope acquire and then reads the rows with plain loads.  The counter is reset by that workgroup, so every
-// launch leaves the counters zero for the next one on the same stream.
-// ---------------------------------------------------------------------------------------------
-struct BnTail {
-  unsigned int* counters;   // one per channel slab; NULL = no tail (partials only)
-  double count;
-  double* sums;             // [2C+1] or NULL
-  float* sums_f32;          // [2C] or NULL
-  const float* gamma;       // coefficient part: mean != NULL
-  const float* beta;
-  float eps, momentum;
-  int legacy_clamp;
-  float* running_mean;
-  float* running_var;
-  float* mean;
-  float* inv_std;
-  float* scale;
-  float* shift;
-};
-
-__device__ __forceinline__ bool arrives_last(unsigned int* counter, unsigned int expected) {
-  __shared__ unsigned int last_flag;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned int t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool last = t + 1u == expected;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    last_flag = last ? 1u : 0u;
-  }
-  __syncthreads();
-  return last_flag != 0u;
-}
-
-// run by all BN_THREADS threads of the last workgroup of slab [c_base, c_base + Cs), Cs <= 64
-__device__ __forceinline__ void slab_tail(const double* __restrict__ partials, int rows, int C, int c_base, int Cs,
-                                          const BnTail& t) {
-  __shared__ double red[16][17];
-  __shared__ double colsum[128];
-  const int j = threadIdx.x & 15, ph = threadIdx.x >> 4;
-  const int n2 = 2 * C;
-  for (int g = 0; g * 16 < 2 * Cs; ++g) {
-    const int col = g * 16 + j;           // column of the slab: which * Cs + channel
-    double s = 0.0;
-    if (col < 2 * Cs) {
-      const int which = col / Cs, cl = col - which * Cs;
-      const double* p = partials + which * C + c_base + cl;
-#pragma unroll 4
-      for (int r = ph; r < rows; r += 16) s += p[(size_t)r * n2];
-    }
-    red[ph][j] = s;
-    __syncthreads();
-    if (threadIdx.x < 16 && col < 2 * Cs) {
-      double v = 0.0;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) v += red[q][threadIdx.x];
-      colsum[col] = v;
-    }
-    __syncthreads();
-  }
-  if ((int)threadIdx.x < Cs) {
-    const int c = c_base + threadIdx.x;
-    const double s = colsum[threadIdx.x], q = colsum[Cs + threadIdx.x];
-    if (t.sums) {
-      t.sums[c] = s;
-      t.sums[C + c] = q;
-    }
-    if (t.sums_f32) {
-      t.sums_f32[c] = (float)s;
-      t.sums_f32[C + c] = (float)q;
-    }
-    if (t.mean)
-      bn_coeff_one(s, q, t.count, c, t.gamma, t.beta, t.eps, t.momentum, t.legacy_clamp, t.running_mean, t.running_var,
-                   t.mean, t.inv_std, t.scale, t.shift);
-  }
-  if (t.sums && c_base == 0 && threadIdx.x == 0) t.sums[n2] = t.count;
-}
-
 template <typename TX, int VEC>
 __global__ __launch_bounds__(BN_THREADS) void bn_stats_pm_kernel(const TX* __restrict__ x, int ld, long long M, int C,
-                                                                  int slab, double* __restrict__ partials,
-                                                                  const BnTail tail) {
+                                                                  int slab, double* __restrict__ partials) {
   const PmThread t = pm_thread<VEC>(C, M, slab);
   // fp64 accumulation: squares of fp32 values are exact in fp64, so E[x^2] - E[x]^2 loses nothing
   double a[VEC], b[VEC];
@@ -293,8 +179,6 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_pm_kernel(const TX* __res
     }
   }
   block_reduce_pm<VEC, double>(a, b, t, partials + (size_t)blockIdx.x * 2 * C, C);
-  if (tail.counters && arrives_last(tail.counters + blockIdx.y, gridDim.x))
-    slab_tail(partials, (int)gridDim.x, C, t.c_base, t.Cs, tail);
 }
 
 // g = dz * mask * mask_scale * [activation > 0]; the activation is x*scale+shift, or, for layers that add a
@@ -323,7 +207,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_pm_kernel(
     const TG* __restrict__ dz, int dz_ld, const TX* __restrict__ x, int x_ld, long long M, int C,
     const float* __restrict__ mean, const float* __restrict__ inv_std, const float* __restrict__ scale,
     const float* __restrict__ shift, int relu, const uint8_t* __restrict__ mask, float mask_scale,
-    const TG* __restrict__ act, int act_ld, int slab, double* __restrict__ partials, const BnTail tail) {
+    const TG* __restrict__ act, int act_ld, int slab, double* __restrict__ partials) {
   const PmThread t = pm_thread<VEC>(C, M, slab);
   extern __shared__ float cf[];  // [4][Cs]: mean, inv_std, scale, shift of the slab, loaded once per workgroup
   for (int i = threadIdx.x; i < t.Cs; i += BN_THREADS) {
@@ -378,8 +262,6 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_pm_kernel(
     }
   }
   block_reduce_pm<VEC, float>(a, b, t, partials + (size_t)blockIdx.x * 2 * C, C);
-  if (tail.counters && arrives_last(tail.counters + blockIdx.y, gridDim.x))
-    slab_tail(partials, (int)gridDim.x, C, t.c_base, t.Cs, tail);
 }
 
 template <typename TX, typename TY, int VEC, bool RES>
@@ -607,6 +489,29 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const double* __restrict
   if (blockIdx.x == 0 && threadIdx.x == 0) sums[n2] = count;
 }
 
+// global sums of one channel -> mean, inv_std, running statistics, scale, shift
+__device__ __forceinline__ void bn_coeff_one(double s, double q, double cnt, int c, const float* gamma, const float* beta,
+                                             float eps, float momentum, int legacy_clamp, float* running_mean,
+                                             float* running_var, float* mean, float* inv_std, float* scale,
+                                             float* shift) {
+  // sums are fp64 end to end (exact squares, fp64 accumulation), so this cancellation is harmless
+  const double mu = s / cnt;
+  double sumvar = q - s * mu;
+  if (sumvar < 0.0) sumvar = 0.0;
+  const double var_b = sumvar / cnt;
+  const double var_u = sumvar / (cnt - 1.0);
+  const double is = legacy_clamp ? 1.0 / sqrt(var_b > (double)eps ? var_b : (double)eps) : 1.0 / sqrt(var_b + (double)eps);
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)var_u;
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float muf = (float)mu, isf = (float)is;
+  mean[c] = muf;
+  inv_std[c] = isf;
+  const float sc = g * isf;
+  scale[c] = sc;
+  shift[c] = b - muf * sc;
+}
+
 __global__ void bn_coeffs_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
                                  const float* __restrict__ beta, float eps, float momentum, int legacy_clamp,
                                  float* __restrict__ running_mean, float* __restrict__ running_var,
@@ -766,27 +671,8 @@ extern "C" int segk_bn_stat_rows(int layout, int N, int C, int HW) {
   return layout == SEGK_PM ? pm_rows((long long)N * HW, C) : nchw_rows(N, HW);
 }
 
-static BnTail no_tail() {
-  BnTail t = {};
-  return t;
-}
-
-// C tail description -> device form (validated)
-static int make_tail(const segk_bn_tail* a, int C, BnTail& t, const char* name) {
-  SEGK_REQUIRE(a && a->counters && a->count > 0.0, "%s: tail needs counters and a positive count", name);
-  SEGK_REQUIRE(a->sums || a->mean, "%s: tail with nothing to write", name);
-  SEGK_REQUIRE(!a->mean || (a->inv_std && a->scale && a->shift), "%s: coefficient outputs come together", name);
-  t.counters = a->counters; t.count = a->count; t.sums = a->sums; t.sums_f32 = a->sums_f32;
-  t.gamma = a->gamma; t.beta = a->beta; t.eps = a->eps; t.momentum = a->momentum; t.legacy_clamp = a->legacy_clamp;
-  t.running_mean = a->running_mean; t.running_var = a->running_var;
-  t.mean = a->mean; t.inv_std = a->inv_std; t.scale = a->scale; t.shift = a->shift;
-  return SEGK_OK;
-}
-
-extern "C" int segk_bn_tail_counters(int C) { return C > 0 ? ceil_div(C, pm_stat_slab(C)) : SEGK_INVALID_ARG; }
-
-static int bn_stats_impl(const void* x, int dtype, int layout, int N, int C, int HW, int ld, double* partials,
-                         const BnTail& tail, segk_stream_t stream) {
+extern "C" int segk_bn_stats(const void* x, int dtype, int layout, int N, int C, int HW, int ld, double* partials,
+                             segk_stream_t stream) {
   SEGK_REQUIRE(x && partials && valid_dtype(dtype), "bn_stats: null pointer or bad dtype");
   BN_COMMON_CHECK("bn_stats");
   hipStream_t st = (hipStream_t)stream;
@@ -797,28 +683,14 @@ static int bn_stats_impl(const void* x, int dtype, int layout, int N, int C, int
     const int vec = pm_vec(C, {ld}, {{x, dtype}}, nullptr);
     const int slab = pm_stat_slab(C);
     SEGK_DISPATCH_DTYPE(dtype, T, SEGK_DISPATCH_VEC(vec, V, (bn_stats_pm_kernel<T, V><<<dim3(rows, ceil_div(C, slab)), BN_THREADS, 0, st>>>(
-        (const T*)x, ld, M, C, slab, partials, tail))));
+        (const T*)x, ld, M, C, slab, partials))));
   } else {
-    SEGK_REQUIRE(!tail.counters, "bn_stats: the fused tail needs the pixel-major layout");
     SEGK_REQUIRE(C <= 2147483647, "bn_stats: C too large");
     dim3 grid(C, nchw_rows(N, HW));
     SEGK_DISPATCH_DTYPE(dtype, T, (bn_stats_nchw_kernel<T><<<grid, BN_THREADS, 0, st>>>((const T*)x, N, C, HW, partials)));
   }
   SEGK_CHECK_LAUNCH("bn_stats");
   return SEGK_OK;
-}
-
-extern "C" int segk_bn_stats(const void* x, int dtype, int layout, int N, int C, int HW, int ld, double* partials,
-                             segk_stream_t stream) {
-  return bn_stats_impl(x, dtype, layout, N, C, HW, ld, partials, no_tail(), stream);
-}
-
-extern "C" int segk_bn_stats_tail(const void* x, int dtype, int N, int C, int HW, int ld, double* partials,
-                                  const segk_bn_tail* tail, segk_stream_t stream) {
-  BnTail t = no_tail();
-  const int rc = make_tail(tail, C, t, "bn_stats_tail");
-  if (rc != SEGK_OK) return rc;
-  return bn_stats_impl(x, dtype, SEGK_PM, N, C, HW, ld, partials, t, stream);
 }
 
 extern "C" int segk_bn_reduce(const double* partials, int rows, int C, double count, double* sums, float* sums_f32,
@@ -907,11 +779,11 @@ extern "C" int segk_bn_apply(const void* x, int x_dtype, int x_ld, void* y, int 
   return SEGK_OK;
 }
 
-static int bn_bwd_stats_impl(const void* dz, int dz_dtype, int dz_ld, const void* x, int x_dtype, int x_ld,
-                             int layout, int N, int C, int HW, const float* mean, const float* inv_std,
-                             const float* scale, const float* shift, int relu, const uint8_t* mask,
-                             float mask_scale, const void* act, int act_ld, double* partials, const BnTail& tail,
-                             segk_stream_t stream) {
+extern "C" int segk_bn_bwd_stats(const void* dz, int dz_dtype, int dz_ld, const void* x, int x_dtype, int x_ld,
+                                 int layout, int N, int C, int HW, const float* mean, const float* inv_std,
+                                 const float* scale, const float* shift, int relu, const uint8_t* mask,
+                                 float mask_scale, const void* act, int act_ld, double* partials,
+                                 segk_stream_t stream) {
   SEGK_REQUIRE(dz && x && mean && inv_std && scale && shift && partials && valid_dtype(dz_dtype) && valid_dtype(x_dtype),
                "bn_bwd_stats: null pointer or bad dtype");
   BN_COMMON_CHECK("bn_bwd_stats");
@@ -930,11 +802,11 @@ static int bn_bwd_stats_impl(const void* dz, int dz_dtype, int dz_ld, const void
     if (act)                                                                                                        \
       bn_bwd_stats_pm_kernel<TG, TX, V, true><<<grid_, BN_THREADS, lds, st>>>(                                      \
           (const TG*)dz, dz_ld, (const TX*)x, x_ld, M, C, mean, inv_std, scale, shift, relu, mask, mask_scale,      \
-          (const TG*)act, act_ld, slab, partials, tail);                                                            \
+          (const TG*)act, act_ld, slab, partials);                                                                  \
     else                                                                                                            \
       bn_bwd_stats_pm_kernel<TG, TX, V, false><<<grid_, BN_THREADS, lds, st>>>(                                     \
           (const TG*)dz, dz_ld, (const TX*)x, x_ld, M, C, mean, inv_std, scale, shift, relu, mask, mask_scale,      \
-          nullptr, 0, slab, partials, tail);                                                                        \
+          nullptr, 0, slab, partials);                                                                              \
   })
     if (dz_dtype == SEGK_BF16 && x_dtype == SEGK_BF16) { LAUNCH_BS(bf16_t, bf16_t); }
     else if (dz_dtype == SEGK_BF16) { LAUNCH_BS(bf16_t, float); }
@@ -943,7 +815,6 @@ static int bn_bwd_stats_impl(const void* dz, int dz_dtype, int dz_ld, const void
 #undef LAUNCH_BS
   } else {
     SEGK_REQUIRE(!act, "bn_bwd_stats: a stored activation needs the pixel-major layout");
-    SEGK_REQUIRE(!tail.counters, "bn_bwd_stats: the fused tail needs the pixel-major layout");
     dim3 grid(C, nchw_rows(N, HW));
 #define LAUNCH_BS(TG, TX)                                                                                        \
   bn_bwd_stats_nchw_kernel<TG, TX><<<grid, BN_THREADS, 0, st>>>((const TG*)dz, (const TX*)x, N, C, HW, mean, inv_std, \
@@ -956,28 +827,6 @@ static int bn_bwd_stats_impl(const void* dz, int dz_dtype, int dz_ld, const void
   }
   SEGK_CHECK_LAUNCH("bn_bwd_stats");
   return SEGK_OK;
-}
-
-extern "C" int segk_bn_bwd_stats(const void* dz, int dz_dtype, int dz_ld, const void* x, int x_dtype, int x_ld,
-                                 int layout, int N, int C, int HW, const float* mean, const float* inv_std,
-                                 const float* scale, const float* shift, int relu, const uint8_t* mask,
-                                 float mask_scale, const void* act, int act_ld, double* partials,
-                                 segk_stream_t stream) {
-  return bn_bwd_stats_impl(dz, dz_dtype, dz_ld, x, x_dtype, x_ld, layout, N, C, HW, mean, inv_std, scale, shift, relu,
-                           mask, mask_scale, act, act_ld, partials, no_tail(), stream);
-}
-
-extern "C" int segk_bn_bwd_stats_tail(const void* dz, int dz_dtype, int dz_ld, const void* x, int x_dtype, int x_ld,
-                                      int N, int C, int HW, const float* mean, const float* inv_std,
-                                      const float* scale, const float* shift, int relu, const uint8_t* mask,
-                                      float mask_scale, const void* act, int act_ld, double* partials,
-                                      const segk_bn_tail* tail, segk_stream_t stream) {
-  BnTail t = no_tail();
-  const int rc = make_tail(tail, C, t, "bn_bwd_stats_tail");
-  if (rc != SEGK_OK) return rc;
-  SEGK_REQUIRE(!t.mean, "bn_bwd_stats_tail: the backward tail writes sums only");
-  return bn_bwd_stats_impl(dz, dz_dtype, dz_ld, x, x_dtype, x_ld, SEGK_PM, N, C, HW, mean, inv_std, scale, shift, relu,
-                           mask, mask_scale, act, act_ld, partials, t, stream);
 }
 
 extern "C" int segk_bn_bwd_apply(const void* dz, int dz_dtype, int dz_ld, const void* x, int x_dtype, int x_ld, void* dx,

@@ -35,13 +35,6 @@ class WgradArgs(ctypes.Structure):
                 ("dil", c_int), ("splits", c_int), ("slabs", c_void_p), ("tile", c_int)]
 
 
-class BnTail(ctypes.Structure):
-    _fields_ = [("counters", c_void_p), ("count", ctypes.c_double), ("sums", c_void_p), ("sums_f32", c_void_p),
-                ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("momentum", c_float),
-                ("legacy_clamp", c_int), ("running_mean", c_void_p), ("running_var", c_void_p), ("mean", c_void_p),
-                ("inv_std", c_void_p), ("scale", c_void_p), ("shift", c_void_p)]
-
-
 class GemmTerm(ctypes.Structure):
     _fields_ = [("A", c_void_p), ("a_batch", c_ll), ("lda", c_int), ("B", c_void_p), ("b_batch", c_ll), ("ldb", c_int),
                 ("K", c_int)]
@@ -86,11 +79,6 @@ SIGNATURES = {
     "segk_dot_partial_rows": [c_ll],
     "segk_bn_stats": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "segk_bn_stat_rows": [c_int, c_int, c_int, c_int],
-    "segk_bn_tail_counters": [c_int],
-    "segk_bn_stats_tail": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, ctypes.POINTER(BnTail), c_void_p],
-    "segk_bn_bwd_stats_tail": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
-                               c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p,
-                               ctypes.POINTER(BnTail), c_void_p],
     "segk_bn_reduce": [c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p, c_void_p],
     "segk_bn_coeffs": [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p,
                        c_void_p, c_void_p, c_void_p, c_int, c_void_p],

@@ -194,7 +194,8 @@ def unit_backward(rec, dz, need_dw=True, dw_like=None):
     N, H, W = rec.geom
     M = N * H * W
     C = rec.Cout
-    local, dgb = ops.bn_bwd_sums_fused(dz, rec.raw, rec.coef, rec.relu, rec.mask, rec.mask_scale)
+    partials, cnt = ops.bn_bwd_stat_partials(dz, rec.raw, rec.coef, PM, rec.relu, rec.mask, rec.mask_scale)
+    local, dgb = ops.bn_reduce(partials, cnt, want_f32=True)
     dbeta, dgamma = dgb[0], dgb[1]
     gs = _global_sums(local, rec.sync and rec.training)
     cpad = ops.round_up(C, 32)
@@ -569,18 +570,7 @@ class SyncBNFunction(torch.autograd.Function):
             rv = pm_view_of(residual) if layout == PM and residual.shape == x.shape else None
             if rv is None or rv.dtype != x.dtype or xv.dtype != x.dtype:
                 raise ValueError("the fused residual form needs channels_last input and residual of one dtype")
-        if spec.training and layout == PM:
-            # statistics, their reduction and (without an exchange between ranks) the coefficients in one launch
-            cnt = float(xv.shape[0])
-            _check_count(cnt * (parallel.world_size() if spec.sync else 1))
-            if spec.sync:
-                sums = _global_sums(ops.bn_stats_fused(xv, want="sums")[0], True)
-                coef = ops.bn_coeffs(sums, gamma, beta, spec.eps, spec.momentum, spec.running_mean, spec.running_var,
-                                     legacy_clamp=config.legacy_clamp_eps())
-            else:
-                coef = ops.bn_stats_fused(xv, gamma, beta, spec.eps, spec.momentum, spec.running_mean,
-                                          spec.running_var)[0]
-        elif spec.training:
+        if spec.training:
             partials, cnt = ops.bn_stat_partials(xv, layout)
             coef = _train_coeffs(partials, cnt, spec, gamma, beta)
         else:
@@ -617,11 +607,8 @@ class SyncBNFunction(torch.autograd.Function):
             gv = g.to(xv.dtype).contiguous()
             dx = torch.empty_like(xv)
             dxv = dx
-        if layout == PM:
-            local, dgb = ops.bn_bwd_sums_fused(gv, xv, coef, relu, act=act)
-        else:
-            partials, cnt = ops.bn_bwd_stat_partials(gv, xv, coef, layout, relu, act=act)
-            local, dgb = ops.bn_reduce(partials, cnt, want_f32=True)
+        partials, cnt = ops.bn_bwd_stat_partials(gv, xv, coef, layout, relu, act=act)
+        local, dgb = ops.bn_reduce(partials, cnt, want_f32=True)
         dbeta, dgamma = dgb[0], dgb[1]
         gs = _global_sums(local, sync and training)
         ops.bn_bwd_apply(gv, xv, dxv, coef, gs, layout, relu, eval_mode=not training, act=act,

@@ -495,85 +495,6 @@ def bn_stat_partials(x, layout):
     return partials, float(N * HW)
 
 
-_TAIL_COUNTERS = {}
-
-
-def _tail_counters(device, n):
-    """Zeroed ticket counters for the fused statistics tails, one buffer per (device, stream): launches ordered on a
-    stream leave them zero for each other."""
-    key = (device.index, _stream().value)
-    buf = _TAIL_COUNTERS.get(key)
-    if buf is None or buf.numel() < n:
-        buf = torch.zeros((max(n, 64),), dtype=torch.int32, device=device)
-        _TAIL_COUNTERS[key] = buf
-    return buf
-
-
-def _tail(x_device, C, count, sums=None, sums_f32=None, coef=None, gamma=None, beta=None, eps=0.0, momentum=0.0,
-          running_mean=None, running_var=None, legacy_clamp=False):
-    t = _lib.BnTail()
-    t.counters = _tail_counters(x_device, call("segk_bn_tail_counters", C)).data_ptr()
-    t.count = count
-    t.sums = sums.data_ptr() if sums is not None else None
-    t.sums_f32 = sums_f32.data_ptr() if sums_f32 is not None else None
-    if coef is not None:
-        base, step = coef.data_ptr(), coef.shape[1] * 4
-        t.mean, t.inv_std, t.scale, t.shift = base, base + step, base + 2 * step, base + 3 * step
-        t.gamma = gamma.data_ptr() if gamma is not None else None
-        t.beta = beta.data_ptr() if beta is not None else None
-        t.eps, t.momentum, t.legacy_clamp = eps, momentum, 1 if legacy_clamp else 0
-        t.running_mean = running_mean.data_ptr() if running_mean is not None else None
-        t.running_var = running_var.data_ptr() if running_var is not None else None
-    return t
-
-
-def bn_stats_fused(x, gamma=None, beta=None, eps=0.0, momentum=0.0, running_mean=None, running_var=None,
-                   legacy_clamp=False, want="coef"):
-    """Pixel-major statistics with the reduction in the same launch.  want="coef": -> coef [4, C] (mean, inv_std,
-    scale, shift; running statistics updated) for layers whose statistics are not exchanged; want="sums": -> the
-    [2C+1] float64 vector that ranks all-reduce.  Second result: elements per channel."""
-    _dev(x, gamma, beta, running_mean, running_var)
-    N, C, HW, ld = _bn_geom(x, PM)
-    rows = call("segk_bn_stat_rows", PM, N, C, HW)
-    partials = torch.empty((rows, 2, C), dtype=torch.float64, device=x.device)
-    count = float(N * HW)
-    if want == "coef":
-        out = torch.empty((4, C), dtype=torch.float32, device=x.device)
-        t = _tail(x.device, C, count, coef=out, gamma=gamma, beta=beta, eps=eps, momentum=momentum,
-                  running_mean=running_mean, running_var=running_var, legacy_clamp=legacy_clamp)
-    else:
-        out = torch.empty((2 * C + 1,), dtype=torch.float64, device=x.device)
-        t = _tail(x.device, C, count, sums=out)
-    t0 = _hbm_start()
-    call("segk_bn_stats_tail", _ptr(x), _dt(x), N, C, HW, ld, _ptr(partials), ctypes.byref(t), _stream())
-    _hbm_stop("bn_stats", _nbytes(x), t0)
-    return out, count
-
-
-def bn_bwd_sums_fused(dz, x, coef, relu, mask=None, mask_scale=1.0, act=None):
-    """bn_bwd_stat_partials + bn_reduce(want_f32=True) in one launch (pixel-major): -> ([2C+1] float64 local sums,
-    [2, C] float32 = d(beta), d(gamma) of this rank)."""
-    _dev(dz, x, coef, mask, act)
-    N, C, HW, x_ld = _bn_geom(x, PM)
-    dz_ld = _pm(dz)[0]
-    _mask_check(mask, x)
-    if act is not None and act.dtype != dz.dtype:
-        raise ValueError("the stored activation has the gradient's dtype")
-    ap, act_ld = _pm_operand(act, x, "stored activation", PM)
-    rows = call("segk_bn_stat_rows", PM, N, C, HW)
-    partials = torch.empty((rows, 2, C), dtype=torch.float64, device=x.device)
-    sums = torch.empty((2 * C + 1,), dtype=torch.float64, device=x.device)
-    f32 = torch.empty((2, C), dtype=torch.float32, device=x.device)
-    t = _tail(x.device, C, float(N * HW), sums=sums, sums_f32=f32)
-    r = _row_ptrs(coef)
-    t0 = _hbm_start()
-    call("segk_bn_bwd_stats_tail", _ptr(dz), _dt(dz), dz_ld, _ptr(x), _dt(x), x_ld, N, C, HW, r[0], r[1], r[2], r[3],
-         1 if relu else 0, _ptr(mask), ctypes.c_float(mask_scale), ap, act_ld, _ptr(partials), ctypes.byref(t),
-         _stream())
-    _hbm_stop("bn_bwd_stats", _nbytes(dz, x, act, mask), t0)
-    return sums, f32
-
-
 def bn_local_sums(x, layout):
     """[2C+1] float64: per-channel sum, sum of squares, element count of THIS rank's tensor."""
     partials, count = bn_stat_partials(x, layout)

@@ -540,34 +540,3 @@ def test_bn_residual_relu_fused(ops, dtype, tol):
     assert relerr(sums[:C], br.grad) < tol
     xhat_scale = relerr(sums[C:2 * C] * coef[1].double(), gr.grad * coef[1].double())  # sum g*xhat = dgamma
     assert xhat_scale < tol
-
-
-def test_bn_fused_tail_is_bit_identical_to_separate_reduce(ops):
-    """segk_bn_stats_tail / segk_bn_bwd_stats_tail (the last workgroup of a channel slab reduces in the same launch)
-    against stats -> reduce -> coeffs as three launches: identical bits, many launches in a row on shared counters."""
-    dev, PM = "cuda", 0
-    g = torch.Generator(device="cpu").manual_seed(5)
-    for (M, C, dt) in ((17424, 1024, torch.bfloat16), (4225, 256, torch.bfloat16), (300, 48, torch.float32),
-                       (70001, 64, torch.float32), (129, 2048, torch.bfloat16)):
-        x = (torch.randn((M, C), generator=g) * 2 + 0.3).to(dev).to(dt)
-        dz = torch.randn((M, C), generator=g).to(dev).to(dt)
-        act = torch.randn((M, C), generator=g).to(dev).to(dt)
-        gamma = (torch.rand((C,), generator=g) + 0.5).to(dev)
-        beta = torch.randn((C,), generator=g).to(dev)
-        for rep in range(3):
-            rm1, rv1 = torch.zeros(C, device=dev), torch.ones(C, device=dev)
-            rm2, rv2 = rm1.clone(), rv1.clone()
-            partials, cnt = ops.bn_stat_partials(x, PM)
-            ref = ops.bn_reduce_coeffs(partials, cnt, gamma, beta, 1e-5, 0.1, rm1, rv1)
-            got, cnt2 = ops.bn_stats_fused(x, gamma, beta, 1e-5, 0.1, rm2, rv2)
-            assert cnt == cnt2 and torch.equal(ref, got) and torch.equal(rm1, rm2) and torch.equal(rv1, rv2)
-            sums_ref = ops.bn_reduce(partials, cnt)
-            sums, _ = ops.bn_stats_fused(x, want="sums")
-            assert torch.equal(sums_ref, sums)
-            for a in (None, act):
-                p2, c2 = ops.bn_bwd_stat_partials(dz, x, ref, PM, True, act=a)
-                l_ref, f_ref = ops.bn_reduce(p2, c2, want_f32=True)
-                l_got, f_got = ops.bn_bwd_sums_fused(dz, x, ref, True, act=a)
-                assert torch.equal(l_ref, l_got) and torch.equal(f_ref, f_got)
-    torch.cuda.synchronize()
-    assert all(int(b.abs().sum()) == 0 for b in ops._TAIL_COUNTERS.values())   # every launch left its counters zero
