@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--optimizer", choices=["hip", "torch"], default="hip",
                     help="hip: segk.optim.SGD (one launch per parameter group; the bf16 feeder's convolution weights "
                          "are held in bf16 with fp32 masters in the optimizer); torch: torch.optim.SGD on fp32 weights")
+    ap.add_argument("--feeder-conv", choices=["auto", "hip", "torch"], default=None,
+                    help="segk.config.set_feeder_conv: which kernels run the feeder's layer-3/4 3x3 convolutions "
+                         "(default: the package default)")
     ap.add_argument("--sync-bn", choices=["auto", "on", "off"], default="on",
                     help="SynchronizedBatchNorm2d (HIP) in every layer, the reference's --sync-bn (train.py:321-322); "
                          "auto = only with more than one rank, its default when the flag is not given "
@@ -273,6 +276,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if args.feeder_conv is not None:
+        config.set_feeder_conv(args.feeder_conv)
     search = not args.no_miopen_benchmark
     if rank == 0:
         heartbeat()
