@@ -308,7 +308,7 @@ int segk_ce_bwd(const float* logits, const float* target, const float* weight, c
 
 /* segk_ce_fwd for callers that cannot allocate device memory or carry a workspace (code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.
- * The partial rows live in a fixed 16 KiB device array inside the library (one copy per GPU, held until the
+ * The partial rows live in a fixed 64 KiB device array inside the library (one copy per GPU, held until the
  * process ends); the call allocates nothing.  Same results as segk_ce_fwd, bit for bit.  At most
  * segk_ce_fwd_static_max_pixels() = 2^25 pixels (N*HW); more returns SEGK_UNSUPPORTED_SHAPE.  All calls on one
  * GPU share that array: calls that overlap on one GPU (two streams, two threads) race; calls ordered on one

@@ -10,7 +10,7 @@
 namespace segk {
 
 constexpr int CE_THREADS = 256;
-constexpr int CE_MAX_ROWS = 2048;
+constexpr int CE_MAX_ROWS = 8192;
 
 static int ce_rows(long long pixels) {
   long long r = (pixels + CE_THREADS - 1) / CE_THREADS;
@@ -31,22 +31,33 @@ __global__ __launch_bounds__(CE_THREADS) void ce_fwd_kernel(const float* __restr
     const long long n = i / HW;
     const int p = (int)(i - n * HW);
     const float* l = logits + (size_t)n * K * HW + p;
-    float m = -INFINITY, s = 0.f;
-    for (int k = 0; k < K; ++k) {
-      const float v = l[(size_t)k * HW];
-      if (v > m) {
-        s = s * __expf(m - v) + 1.f;
-        m = v;
-      } else {
-        s += __expf(v - m);
+    // online log-sum-exp over groups of eight class planes: the eight loads of a group are independent, so a thread
+    // keeps eight requests in flight instead of one per branch of the running maximum.  The label's logit is
+    // picked from the registers on the way (a per-lane gather would cost a cache line per lane).
+    const int t = label_of(target[i]);
+    float m = -INFINITY, s = 0.f, vt = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = k0 + u < K ? l[(size_t)(k0 + u) * HW] : -INFINITY;
+      float gm = v[0];
+#pragma unroll
+      for (int u = 1; u < 8; ++u) gm = fmaxf(gm, v[u]);
+      if (gm > m) {
+        s *= __expf(m - gm);
+        m = gm;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        s += __expf(v[u] - m);
+        if (k0 + u == t) vt = v[u];
       }
     }
     const float lse = m + __logf(s);
     lse_out[i] = lse;
-    const int t = label_of(target[i]);
     if (t != ignore_index && t >= 0 && t < K) {
       const float w = weight ? weight[t] : 1.f;
-      loss += w * (lse - l[(size_t)t * HW]);
+      loss += w * (lse - vt);
       wsum += w;
     }
   }
@@ -123,12 +134,17 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
     const float* l = logits + (size_t)n * K * HW + p;
     float best = l[0];
     int bi = 0;
-    for (int k = 1; k < K; ++k) {
-      const float v = l[(size_t)k * HW];
-      // first maximal index; a NaN is maximal (and the first NaN wins)
-      if (v > best || (v != v && best == best)) {
-        best = v;
-        bi = k;
+    for (int k0 = 1; k0 < K; k0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = k0 + u < K ? l[(size_t)(k0 + u) * HW] : 0.f;   // eight loads in flight
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        // first maximal index; a NaN is maximal (and the first NaN wins)
+        if (k0 + u < K && (v[u] > best || (v[u] != v[u] && best == best))) {
+          best = v[u];
+          bi = k0 + u;
+        }
       }
     }
     pred[i] = bi;
@@ -140,42 +156,62 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
 // reproducible).  Each block sees < 2^32 pixels.
 template <bool GT_I64, bool USE_LDS>
 __global__ __launch_bounds__(256) void confmat_kernel(const void* __restrict__ gt_, const int64_t* __restrict__ pred,
-                                                       long long count, int K, unsigned long long* __restrict__ cm) {
+                                                       long long count, int K, int copies,
+                                                       unsigned long long* __restrict__ cm) {
+  // `copies` (a power of two) private histograms per block, chosen by lane: neighbouring pixels mostly fall into the
+  // same bin, and LDS atomics of one wavefront on one address are served one after the other
   extern __shared__ __attribute__((aligned(16))) unsigned int bins[];
   const int nb = K * K + 1;
   if (USE_LDS) {
-    for (int b = threadIdx.x; b < nb; b += 256) bins[b] = 0u;
+    for (int b = threadIdx.x; b < nb * copies; b += 256) bins[b] = 0u;
     __syncthreads();
   }
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
-    long long g;
-    bool ok;
+  unsigned int* mine = bins + (threadIdx.x & (copies - 1)) * nb;
+  auto label = [&](long long i, bool& ok) -> long long {
     if (GT_I64) {
-      g = ((const int64_t*)gt_)[i];
+      const long long g = ((const int64_t*)gt_)[i];
       ok = g >= 0 && g < K;
-    } else {
-      const float f = ((const float*)gt_)[i];
-      ok = f >= 0.f && f < (float)K;
-      g = ok ? (long long)f : 0;
+      return g;
     }
-    if (!ok) continue;
-    const long long pr = pred[i];
+    const float f = ((const float*)gt_)[i];
+    ok = f >= 0.f && f < (float)K;
+    return ok ? (long long)f : 0;
+  };
+  auto count_one = [&](long long g, bool ok, long long pr) {
+    if (!ok) return;
     const int b = (pr >= 0 && pr < K) ? (int)(g * K + pr) : K * K;
     if (USE_LDS)
-      atomicAdd(&bins[b], 1u);
+      atomicAdd(&mine[b], 1u);
     else
       atomicAdd(&cm[b], 1ull);
+  };
+  const long long step = (long long)gridDim.x * 256;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * step < count; i += 4 * step) {   // eight loads in flight before the first atomic
+    long long g[4], pr[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      g[u] = label(i + u * step, ok[u]);
+      pr[u] = pred[i + u * step];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) count_one(g[u], ok[u], pr[u]);
+  }
+  for (; i < count; i += step) {
+    bool ok;
+    const long long g = label(i, ok);
+    count_one(g, ok, pred[i]);
   }
   if (USE_LDS) {
     __syncthreads();
     for (int b = threadIdx.x; b < nb; b += 256) {
-      const unsigned int v = bins[b];
+      unsigned int v = 0u;
+      for (int c = 0; c < copies; ++c) v += bins[c * nb + b];
       if (v) atomicAdd(&cm[b], (unsigned long long)v);
     }
   }
 }
-
-
 
 int ce_partial_rows(long long pixels) { return ce_rows(pixels); }
 int launch_ce_finish(const float* partials, int rows, float* sums, hipStream_t st) {
@@ -208,7 +244,7 @@ extern "C" int segk_ce_fwd(const float* logits, const float* target, const float
 // The partial rows of segk_ce_fwd live in a file-scope device array instead of a caller workspace.  Every GPU
 // the library runs on holds its own copy at its own address, found once per device with hipGetSymbolAddress
 // (host code never passes the array's name to a kernel).
-constexpr long long CE_STATIC_MAX_PIXELS = 1ll << 25;  // <= 64 pixels per thread of the 2048 x 256 grid
+constexpr long long CE_STATIC_MAX_PIXELS = 1ll << 25;  // <= 16 pixels per thread of the 8192 x 256 grid
 static __device__ __align__(256) float scratch[2 * CE_MAX_ROWS];
 
 namespace {
@@ -293,8 +329,11 @@ extern "C" int segk_confmat(const void* gt, int gt_is_i64, const int64_t* pred, 
   SEGK_REQUIRE(gt && pred && cm, "confmat: null pointer");
   SEGK_REQUIRE(count >= 0 && K > 0 && K <= 32768, "confmat: bad shape count=%lld K=%d", count, K);
   if (count == 0) return SEGK_OK;
-  const size_t lds = ((size_t)K * K + 1) * sizeof(unsigned int);
-  const bool use_lds = lds <= 60 * 1024;
+  const size_t one = ((size_t)K * K + 1) * sizeof(unsigned int);
+  const bool use_lds = one <= 60 * 1024;
+  int copies = 1;
+  while (copies < 16 && one * copies * 2 <= 32 * 1024) copies *= 2;
+  const size_t lds = one * copies;
   // each block must see fewer than 2^32 pixels; 1024 blocks of >= 16K pixels keep the flush cost small
   long long blocks = (count + 16383) / 16384;
   if (blocks < 1) blocks = 1;
@@ -303,14 +342,14 @@ extern "C" int segk_confmat(const void* gt, int gt_is_i64, const int64_t* pred, 
   unsigned long long* c = (unsigned long long*)cm;
   if (use_lds) {
     if (gt_is_i64)
-      confmat_kernel<true, true><<<(int)blocks, 256, lds, st>>>(gt, pred, count, K, c);
+      confmat_kernel<true, true><<<(int)blocks, 256, lds, st>>>(gt, pred, count, K, copies, c);
     else
-      confmat_kernel<false, true><<<(int)blocks, 256, lds, st>>>(gt, pred, count, K, c);
+      confmat_kernel<false, true><<<(int)blocks, 256, lds, st>>>(gt, pred, count, K, copies, c);
   } else {
     if (gt_is_i64)
-      confmat_kernel<true, false><<<(int)blocks, 256, 0, st>>>(gt, pred, count, K, c);
+      confmat_kernel<true, false><<<(int)blocks, 256, 0, st>>>(gt, pred, count, K, 1, c);
     else
-      confmat_kernel<false, false><<<(int)blocks, 256, 0, st>>>(gt, pred, count, K, c);
+      confmat_kernel<false, false><<<(int)blocks, 256, 0, st>>>(gt, pred, count, K, 1, c);
   }
   SEGK_CHECK_LAUNCH("confmat");
   return SEGK_OK;

@@ -288,27 +288,46 @@ __global__ __launch_bounds__(256) void upsample_bwd_nchw_kernel(const float* __r
 //   rows:  ws[n][c][oy][ix] = sum_ox wx(ox, ix) * dout[n][c][oy][ox]     reads the gradient once, coalesced
 //   cols:  din[n][iy][ix][c] = sum_oy wy(oy, iy) * ws[n][c][oy][ix]      reads the (Wo/Wi times smaller) workspace
 // HBM traffic = gradient + 2 x workspace + result, against ~9 x slower gather kernels that re-read through L2.
-constexpr int UR_ROWS = 4;   // gradient rows per workgroup of the row pass
+// gradient rows per workgroup of the row pass: 16, or 4 for rows too wide for 16 of them in 64 KB of LDS
 
+// A thread owns one source column ix for all rows of the workgroup: the tap weights depend on (ox, ix) only, so they
+// are computed once per workgroup and column, and each output accumulates over ox in ascending order.
+template <int UR_ROWS>
 __global__ __launch_bounds__(256) void upsample_bwd_rows_kernel(const float* __restrict__ dout, long long rows, int Wo,
                                                                 int Wi, float sx, float* __restrict__ ws) {
   extern __shared__ float rowbuf[];  // [UR_ROWS][Wo]
   const long long r0 = (long long)blockIdx.x * UR_ROWS;
   const int nr = (int)(rows - r0 < UR_ROWS ? rows - r0 : UR_ROWS);
   const float* src = dout + r0 * Wo;
-  for (int i = threadIdx.x; i < nr * Wo; i += 256) rowbuf[i] = src[i];
+  const int cnt = nr * Wo;
+  // four independent loads in flight per thread and trip
+  int i = threadIdx.x;
+  for (; i + 768 < cnt; i += 1024) {
+    const float a = src[i], b = src[i + 256], c = src[i + 512], d = src[i + 768];
+    rowbuf[i] = a;
+    rowbuf[i + 256] = b;
+    rowbuf[i + 512] = c;
+    rowbuf[i + 768] = d;
+  }
+  for (; i < cnt; i += 256) rowbuf[i] = src[i];
+  for (int j = cnt + threadIdx.x; j < UR_ROWS * Wo; j += 256) rowbuf[j] = 0.f;   // rows past the end
   __syncthreads();
-  for (int idx = threadIdx.x; idx < nr * Wi; idx += 256) {
-    const int r = idx / Wi, ix = idx - r * Wi;
+  for (int ix = threadIdx.x; ix < Wi; ix += 256) {
     int lo, hi;
     reader_range(ix, sx, Wo, lo, hi);
-    const float* row = rowbuf + r * Wo;
-    float a = 0.f;
+    float a[UR_ROWS];
+#pragma unroll
+    for (int r = 0; r < UR_ROWS; ++r) a[r] = 0.f;
     for (int ox = lo; ox <= hi; ++ox) {
       const float w = tap_weight(ox, ix, sx, Wi);
-      if (w != 0.f) a = fmaf(w, row[ox], a);
+      if (w != 0.f) {
+#pragma unroll
+        for (int r = 0; r < UR_ROWS; ++r) a[r] = fmaf(w, rowbuf[r * Wo + ox], a[r]);
+      }
     }
-    ws[(r0 + r) * Wi + ix] = a;
+#pragma unroll
+    for (int r = 0; r < UR_ROWS; ++r)
+      if (r < nr) ws[(r0 + r) * Wi + ix] = a[r];
   }
 }
 
@@ -323,19 +342,27 @@ __global__ __launch_bounds__(256) void upsample_bwd_cols_kernel(const float* __r
   int lo, hi;
   reader_range(iy, sy, Ho, lo, hi);
   const int ix = x0 + lx;
+  // the eight channels of a thread advance together along oy: eight independent loads per tap row
+  constexpr int CPT = UC_CH / 4;
+  float a[CPT];
+  const float* col[CPT];
 #pragma unroll
-  for (int k = 0; k < UC_CH / 4; ++k) {
-    const int cl = cg * (UC_CH / 4) + k, c = c0 + cl;
-    float a = 0.f;
-    if (c < C && ix < Wi) {
-      const float* col = ws + (((size_t)n * C + c) * Ho) * Wi + ix;
-      for (int oy = lo; oy <= hi; ++oy) {
-        const float w = tap_weight(oy, iy, sy, Hi);
-        if (w != 0.f) a = fmaf(w, col[(size_t)oy * Wi], a);
-      }
-    }
-    outs[lx][cl] = a;
+  for (int k = 0; k < CPT; ++k) {
+    const int c = c0 + cg * CPT + k;
+    a[k] = 0.f;
+    col[k] = (c < C && ix < Wi) ? ws + (((size_t)n * C + c) * Ho) * Wi + ix : nullptr;
   }
+  for (int oy = lo; oy <= hi; ++oy) {
+    const float w = tap_weight(oy, iy, sy, Hi);
+    if (w == 0.f) continue;
+    float v[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) v[k] = col[k] ? col[k][(size_t)oy * Wi] : 0.f;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) a[k] = fmaf(w, v[k], a[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) outs[lx][cg * CPT + k] = a[k];
   __syncthreads();
   const int nch = min(UC_CH, cpad - c0);
   for (int idx = threadIdx.x; idx < UC_PIX * nch; idx += 256) {
@@ -620,10 +647,14 @@ extern "C" int segk_upsample_bwd(const void* dout, int dout_dtype, int dout_layo
   } else if (dout_layout == SEGK_NCHW) {
     SEGK_REQUIRE(dout_dtype == SEGK_F32, "upsample_bwd: the NCHW gradient is fp32");
     const long long rows = (long long)N * C * Ho;
-    if (workspace && (long long)Wo * UR_ROWS * 4 <= 65536 && ceil_div(rows, UR_ROWS) < 2147483647LL &&
+    if (workspace && (long long)Wo * 4 * 4 <= 65536 && ceil_div(rows, 4) < 2147483647LL &&
         (long long)N * Hi <= 65535 && ceil_div(din_cpad, UC_CH) <= 65535) {
-      upsample_bwd_rows_kernel<<<ceil_div(rows, UR_ROWS), 256, (size_t)UR_ROWS * Wo * sizeof(float), st>>>(
-          (const float*)dout, rows, Wo, Wi, sx, workspace);
+      if ((long long)Wo * 16 * 4 <= 65536)
+        upsample_bwd_rows_kernel<16><<<ceil_div(rows, 16), 256, (size_t)16 * Wo * sizeof(float), st>>>(
+            (const float*)dout, rows, Wo, Wi, sx, workspace);
+      else
+        upsample_bwd_rows_kernel<4><<<ceil_div(rows, 4), 256, (size_t)4 * Wo * sizeof(float), st>>>(
+            (const float*)dout, rows, Wo, Wi, sx, workspace);
       SEGK_CHECK_LAUNCH("upsample_bwd rows");
       dim3 grid(ceil_div(Wi, UC_PIX), N * Hi, ceil_div(din_cpad, UC_CH));
       SEGK_DISPATCH_DTYPE(din_dtype, T, (upsample_bwd_cols_kernel<T><<<grid, 256, 0, st>>>(workspace, C, Ho, Hi, Wi, sy, (T*)din,

@@ -37,8 +37,8 @@ def _both(logits, target, weight, ignore_index=255):
 def test_static_scratch_equals_workspace_two_calls_in_a_row():
     dev = "cuda:0"
     torch.cuda.set_device(0)
-    # first call: 2048 partial rows (the whole array); second: 3 rows, so stale rows sit right behind the live ones
-    for shape in ((2, 21, 513, 513), (1, 21, 27, 25)):
+    # first call: 8192 partial rows (the whole array); second: 3 rows, so stale rows sit right behind the live ones
+    for shape in ((8, 21, 513, 513), (1, 21, 27, 25)):
         logits, target = _inputs(11, *shape, dev)
         (s0, l0), (s1, l1) = _both(logits, target, None)
         assert np.array_equal(s0, s1), (shape, s0, s1)
