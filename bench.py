@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--optimizer", choices=["hip", "torch"], default="hip",
                     help="hip: segk.optim.SGD (one launch per parameter group; the bf16 feeder's convolution weights "
                          "are held in bf16 with fp32 masters in the optimizer); torch: torch.optim.SGD on fp32 weights")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="record the training iteration once as a HIP graph and replay it (auto: with one rank and the "
+                         "HIP optimizer; ranks that exchange statistics and gradients issue their steps eagerly)")
     ap.add_argument("--feeder-conv", choices=["auto", "hip", "torch"], default=None,
                     help="segk.config.set_feeder_conv: which kernels run the feeder's layer-3/4 3x3 convolutions "
                          "(default: the package default)")
@@ -278,6 +281,10 @@ def main():
     dev = torch.device("cuda", local)
     if args.feeder_conv is not None:
         config.set_feeder_conv(args.feeder_conv)
+    elif world > 1 or args.graph == "off" or args.optimizer != "hip":
+        # issued launch by launch, the fused convolution + batch-norm units of the feeder cost the host more than
+        # they save the GPU (measured: 36.2 against 34.1 ms/step); replayed from a graph they win (33.4 against 33.8)
+        config.set_feeder_conv("torch")
     search = not args.no_miopen_benchmark
     if rank == 0:
         heartbeat()
@@ -325,8 +332,13 @@ def main():
                                            overlap=world > 1 and args.optimizer == "hip")
         image, target = synthetic_batch(args.batch, args.size, args.classes, dev, 1 + rank)
 
+        use_graph = args.graph == "on" or (args.graph == "auto" and world == 1 and args.optimizer == "hip")
+
         def step(i):
             scheduler(opt, i, 0, 0.0)
+            return body()
+
+        def body():
             opt.zero_grad(set_to_none=True)
             if args.fused_loss:
                 loss = model.forward_loss(image, target)
@@ -341,14 +353,27 @@ def main():
                 opt.step()
             return loss
 
-        progress("%s: model built, %d warm-up steps" % (dtype, warmup))
-        for i in range(warmup):
-            step(i)
-            if i == 0:
-                torch.cuda.synchronize()
-                progress("%s: first step done (MIOpen algorithm search included)" % dtype)
+        progress("%s: model built, %d warm-up steps%s" % (dtype, warmup, ", then recorded as one HIP graph" if use_graph else ""))
+        run = step
+        if use_graph:
+            # one process, no collectives: the iteration is recorded once and replayed (segk.graph); the schedule
+            # stays on the host and reaches the recorded optimizer launch through device memory
+            from segk.graph import GraphedTrainStep
+            stepper = GraphedTrainStep(model, criterion, opt, image, target, warmup=warmup,
+                                       loss_fn=model.forward_loss if args.fused_loss else None)
+            progress("%s: warm-up done (MIOpen algorithm search included), step recorded" % dtype)
+
+            def run(i):
+                scheduler(opt, i, 0, 0.0)
+                return stepper(image, target)
+        else:
+            for i in range(warmup):
+                step(i)
+                if i == 0:
+                    torch.cuda.synchronize()
+                    progress("%s: first step done (MIOpen algorithm search included)" % dtype)
         timer = None
-        if detailed:
+        if detailed and not use_graph:
             timer = ops.KernelTimer()
             ops.TIMER = timer
         torch.cuda.synchronize()
@@ -357,17 +382,27 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            loss = step(warmup + i)
+            loss = run(warmup + i)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         progress("%s: %d timed steps, %.2f ms/step" % (dtype, steps, 1000.0 * elapsed / steps))
-        res = {"final_loss": float(loss.detach()), "feeder_amp": feeder_amp, "conv": None, "hbm": None}
+        res = {"final_loss": float(loss.detach()), "feeder_amp": feeder_amp, "conv": None, "hbm": None,
+               "graph": use_graph}
+        if detailed and use_graph:
+            # the launches of a replayed graph cannot be bracketed one by one: the same number of steps again,
+            # issued eagerly with HIP events around every convolution call, right behind the timed region
+            timer = ops.KernelTimer()
+            ops.TIMER = timer
+            for i in range(steps):
+                step(warmup + steps + i)
+            torch.cuda.synchronize()
+            progress("%s: %d eager steps with per-launch events" % (dtype, steps))
         if timer is not None:
             torch.cuda.synchronize()
-            res["conv"] = timer.summary()   # the convolution figures: timed steps only
+            res["conv"] = timer.summary()   # the convolution figures
             # one extra, untimed step with events around the ~450 memory-bound launches as well (their events
             # would cost the timed region about 1.5 %), then an untimed evaluation leg (train.py:215-219 on the
             # device): class argmax + confusion matrix of the step's logits, and the fused upsample + argmax form
@@ -445,14 +480,21 @@ def main():
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "collectives": ("RCCL (torch.distributed nccl backend)" if backend == "nccl" else backend) if world > 1 else None,
+                       "launch": ("one HIP graph per training iteration (segk.graph.GraphedTrainStep): recorded after the "
+                                  "warm-up, replayed in the timed region; learning-rate schedule on the host"
+                                  if main_res["graph"] else "eager: one host call per kernel launch"),
+                       "feeder_3x3_convs": config.feeder_conv(),
+                       "kernel_timing": ("HIP events around each convolution call in %d eagerly issued steps right after "
+                                         "the timed region (a replayed graph cannot be bracketed per launch)" % args.steps
+                                         if main_res["graph"] else "HIP events around each convolution call inside the "
+                                         "timed region (about 1 %% of the step)") if main_res["conv"] is not None else None,
                        "final_loss": main_res["final_loss"]},
         }
         if main_res["conv"] is not None:
             line.update(conv_rooflines(main_res, args.dtype, args.steps, elapsed))
             if "roofline" in line:
                 calls = main_res["conv"]["conv_fwd_kernel"]["launches"] / float(args.steps)
-                line["roofline"]["traffic"] = measured_traffic(args, ("conv_fwd_dma_kernel", "conv_fwd_kernel",
-                                                                      "conv_fwd_halo_kernel"), calls)
+                line["roofline"]["traffic"] = measured_traffic(args, ("conv_fwd_dma_kernel", "conv_fwd_kernel"), calls)
                 line["roofline"]["traffic_unit"] = ("HBM bytes per segk_conv_fwd call (rocprofv3 FETCH_SIZE x2 + "
                                                     "WRITE_SIZE, profiles/pmc_traffic.json)")
             summ = main_res["hbm"]

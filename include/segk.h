@@ -375,6 +375,10 @@ typedef struct {
 int segk_gather_f32(const segk_gather_chunk* table, int n_chunks, segk_stream_t stream);
 int segk_sgd_step(const segk_sgd_chunk* table, int n_chunks, float lr, float momentum, float weight_decay,
                   segk_stream_t stream);
+/* The same update with {lr, momentum, weight_decay} read from three consecutive floats in device memory, for a
+ * launch recorded in a HIP graph: the poly schedule of utils/lr_scheduler.py:50-73 writes a new learning rate into
+ * param_groups before every iteration (train.py:143), and a recorded launch keeps its by-value arguments. */
+int segk_sgd_step_dev(const segk_sgd_chunk* table, int n_chunks, const float* hyper, segk_stream_t stream);
 
 /* ---- exchange step (one process per GPU) ------------------------------------------------------ */
 /* A process-wide RCCL communicator for hosts without a collective library of their own; it stands where the

@@ -69,6 +69,21 @@ __global__ __launch_bounds__(SGD_THREADS) void sgd_kernel(const segk_sgd_chunk* 
   }
 }
 
+// the same update with the three hyper-parameters read from device memory: a launch recorded in a HIP graph keeps
+// following the learning-rate schedule, which the host writes into `hyper` before each replay
+__global__ __launch_bounds__(SGD_THREADS) void sgd_dev_kernel(const segk_sgd_chunk* __restrict__ table,
+                                                              const float* __restrict__ hyper) {
+  const float lr = hyper[0], momentum = hyper[1], wd = hyper[2];
+  const segk_sgd_chunk c = table[blockIdx.x];
+  const int pd = c.dtype & 0xff, gd = (c.dtype >> 8) & 0xff;
+  if (pd == SEGK_BF16) {
+    if (gd == SEGK_BF16) sgd_chunk<bf16_t, bf16_t>(c, lr, momentum, wd);
+    else sgd_chunk<bf16_t, float>(c, lr, momentum, wd);
+  } else {
+    sgd_chunk<float, float>(c, lr, momentum, wd);
+  }
+}
+
 // dst[i] = (float)src[i] over many tensors: packs gradients of mixed types into a flat fp32 all-reduce bucket
 __global__ __launch_bounds__(SGD_THREADS) void gather_f32_kernel(const segk_gather_chunk* __restrict__ table) {
   const segk_gather_chunk c = table[blockIdx.x];
@@ -91,6 +106,14 @@ extern "C" int segk_sgd_step(const segk_sgd_chunk* table, int n_chunks, float lr
   SEGK_REQUIRE(table && n_chunks > 0, "sgd_step: empty table");
   sgd_kernel<<<n_chunks, SGD_THREADS, 0, (hipStream_t)stream>>>(table, lr, momentum, weight_decay);
   SEGK_CHECK_LAUNCH("sgd_step");
+  return SEGK_OK;
+}
+
+extern "C" int segk_sgd_step_dev(const segk_sgd_chunk* table, int n_chunks, const float* hyper, segk_stream_t stream) {
+  SEGK_REQUIRE(table && n_chunks > 0, "sgd_step_dev: empty table");
+  SEGK_REQUIRE(hyper && ((uintptr_t)hyper & 3) == 0, "sgd_step_dev: hyper must be a 4-byte aligned device pointer");
+  sgd_dev_kernel<<<n_chunks, SGD_THREADS, 0, (hipStream_t)stream>>>(table, hyper);
+  SEGK_CHECK_LAUNCH("sgd_step_dev");
   return SEGK_OK;
 }
 

@@ -4,6 +4,10 @@ A table is a numpy structured array with one row per chunk of at most CHUNK elem
 that never change (parameter addresses, sizes) are filled once; a column that changes every step (gradient
 addresses: autograd allocates new gradient tensors each step) is refilled and the table re-uploaded through a small
 ring of pinned staging buffers, stream-ordered, without a host synchronisation in the steady state.
+
+While the current stream records a HIP graph, an upload becomes a copy node that reads its pinned source again at
+every replay: such an upload gets a staging buffer of its own, kept alive with the table and never rewritten, and
+records no event (an event recorded during a capture cannot be waited for by the host).
 """
 import numpy as np
 import torch
@@ -43,6 +47,10 @@ class StagedTable:
         self.host = [torch.empty(max(table.nbytes, 1), dtype=torch.uint8).pin_memory() for _ in range(_RING)]
         self.events = [None] * _RING
         self.turn = 0
+        # staging buffers for uploads recorded in HIP graphs: allocated here, because pinned memory cannot be
+        # allocated while a stream is capturing; one is used up per recorded upload
+        self.spares = [torch.empty(max(table.nbytes, 1), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.recorded = []
 
     def upload(self, rows=None):
         """Copy the table (or the selected rows) to the device; returns the number of rows uploaded."""
@@ -50,11 +58,19 @@ class StagedTable:
         n = len(t)
         if n == 0:
             return 0
+        raw = torch.from_numpy(np.ascontiguousarray(t).view(np.uint8).reshape(-1))
+        if torch.cuda.is_current_stream_capturing():
+            if not self.spares:
+                raise RuntimeError("this table was already recorded into %d HIP graphs" % len(self.recorded))
+            host = self.spares.pop()
+            host[:raw.numel()].copy_(raw)
+            self.recorded.append(host)
+            self.dev[:raw.numel()].copy_(host[:raw.numel()], non_blocking=True)
+            return n
         slot = self.turn
         self.turn = (self.turn + 1) % _RING
         if self.events[slot] is not None:
             self.events[slot].synchronize()   # the copy that last used this staging buffer has long finished
-        raw = torch.from_numpy(np.ascontiguousarray(t).view(np.uint8).reshape(-1))
         self.host[slot][:raw.numel()].copy_(raw)
         self.dev[:raw.numel()].copy_(self.host[slot][:raw.numel()], non_blocking=True)
         ev = torch.cuda.Event()

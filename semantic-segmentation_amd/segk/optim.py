@@ -10,6 +10,10 @@ runs in bf16): the optimizer keeps their fp32 master copy, takes their bf16 grad
 rounded weight back in the same pass, so no per-step cast kernels remain.  ``full_precision_state_dict`` returns
 a checkpoint with the fp32 masters in place of the bf16 copies.
 
+A step recorded in a HIP graph (``segk.graph.GraphedTrainStep``) reads lr / momentum / weight decay from device
+memory (``segk_sgd_step_dev``); ``sync_hyper()`` writes the current ``param_groups`` values there before a replay,
+so the schedule keeps working although a recorded launch keeps its by-value arguments.
+
 ``step(flat_grads=buckets)`` reads the gradients from the flat fp32 buckets of
 ``segk.parallel.GradientBuckets.reduce_flat()`` instead of ``p.grad`` (data-parallel runs: the all-reduced sums
 are consumed where they lie, nothing is copied back).
@@ -83,6 +87,10 @@ class SGD(torch.optim.Optimizer):
         low = {id(p) for p in low_precision}
         self._groups = None
         self._groups_src = None
+        self._hyper_dev = None    # [groups, 4] fp32 on the device, read by recorded steps
+        self._hyper_host = None   # pinned ring of the same shape
+        self._hyper_turn = 0
+        self._hyper_last = None
         for g in self.param_groups:
             g["params"] = [p for p in g["params"] if p.requires_grad]
             for p in g["params"]:
@@ -104,17 +112,46 @@ class SGD(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, flat_grads=None):
         loss = closure() if closure is not None else None
+        recording = torch.cuda.is_current_stream_capturing()
+        if recording and (self._groups is None or self._groups_src is not flat_grads or self._hyper_dev is None):
+            # the chunk tables and their pinned staging buffers cannot be allocated while a stream is capturing
+            raise RuntimeError("segk.optim.SGD: run one step eagerly and call sync_hyper() before recording a step "
+                               "in a HIP graph")
         if self._groups is None or self._groups_src is not flat_grads:
             self._groups = [_Group(g["params"], self.state, flat_grads) for g in self.param_groups if g["params"]]
             self._groups_src = flat_grads
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         live_groups = [g for g in self.param_groups if g["params"]]
-        for grp, hp in zip(self._groups, live_groups):
+        for k, (grp, hp) in enumerate(zip(self._groups, live_groups)):
             n = grp.refresh()
-            if n:
+            if not n:
+                continue
+            if recording:
+                call("segk_sgd_step_dev", ctypes.c_void_p(grp.staged.ptr()), n,
+                     ctypes.c_void_p(self._hyper_dev[k].data_ptr()), stream)
+            else:
                 call("segk_sgd_step", ctypes.c_void_p(grp.staged.ptr()), n, float(hp["lr"]), float(hp["momentum"]),
                      float(hp["weight_decay"]), stream)
         return loss
+
+    def sync_hyper(self):
+        """Write lr / momentum / weight decay of every (non-empty) parameter group to the device table that recorded
+        steps read.  Stream-ordered on the current stream, no host synchronisation; a no-op while nothing changed."""
+        live_groups = [g for g in self.param_groups if g["params"]]
+        vals = [[float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]), 0.0] for g in live_groups]
+        if self._hyper_dev is None:
+            dev = live_groups[0]["params"][0].device
+            self._hyper_dev = torch.zeros((len(vals), 4), dtype=torch.float32, device=dev)
+            self._hyper_host = [torch.zeros((len(vals), 4), dtype=torch.float32).pin_memory() for _ in range(8)]
+        elif vals == self._hyper_last:
+            return
+        # a ring of pinned rows: a copy still in flight keeps its own source (eight steps of slack, and the copies
+        # are stream-ordered behind one another)
+        host = self._hyper_host[self._hyper_turn]
+        self._hyper_turn = (self._hyper_turn + 1) % len(self._hyper_host)
+        host.copy_(torch.tensor(vals, dtype=torch.float32))
+        self._hyper_dev.copy_(host, non_blocking=True)
+        self._hyper_last = vals
 
     # ---- checkpoints (utils/saver.py:33-60 stores optimizer.state_dict(); train.py:124 loads it back) ----------
     @staticmethod
