@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="record the training iteration once as a HIP graph and replay it (auto: with one rank and the "
                          "HIP optimizer; ranks that exchange statistics and gradients issue their steps eagerly)")
+    ap.add_argument("--overlap-wgrad", choices=["auto", "on", "off"], default="off",
+                    help="segk.config.set_overlap_wgrad: weight gradients on a second HIP stream (auto: with --graph)")
     ap.add_argument("--feeder-conv", choices=["auto", "hip", "torch"], default=None,
                     help="segk.config.set_feeder_conv: which kernels run the feeder's layer-3/4 3x3 convolutions "
                          "(default: the package default)")
@@ -333,6 +335,7 @@ def main():
         image, target = synthetic_batch(args.batch, args.size, args.classes, dev, 1 + rank)
 
         use_graph = args.graph == "on" or (args.graph == "auto" and world == 1 and args.optimizer == "hip")
+        config.set_overlap_wgrad(args.overlap_wgrad == "on" or (args.overlap_wgrad == "auto" and use_graph))
 
         def step(i):
             scheduler(opt, i, 0, 0.0)

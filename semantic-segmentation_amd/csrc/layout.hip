@@ -139,6 +139,46 @@ __global__ void wgrad_finish_kernel(const float* __restrict__ slabs, int splits,
   }
 }
 
+// The same sum for small gradients cut into many parts (the 1x1 convolutions onto 48 or 21 channels at 129 x 129:
+// a 64 KB slab, hundreds of parts so that the multiplication fills the chip).  A workgroup owns 32 co x 8 ci; its
+// eight thread rows each add every eighth part (parts r, r + 8, ... in ascending order), then the eight row sums are
+// added in row order: a fixed order, and eight times the loads in flight of the serial walk above.
+template <typename TD>
+__global__ __launch_bounds__(256) void wgrad_finish_tree_kernel(const float* __restrict__ slabs, int splits, int taps,
+                                                                int Cin, int Cout, TD* __restrict__ dw, long long s_co,
+                                                                long long s_ci, long long s_tap, int Cout_true,
+                                                                int Cin_true) {
+  __shared__ float part[8][8][33];
+  const int tap = blockIdx.z;
+  const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 8;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const size_t slab = (size_t)taps * Cin * Cout;
+  const int co = co0 + tx;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  if (co < Cout) {
+    for (int sp = ty; sp < splits; sp += 8) {
+      const float* p = slabs + sp * slab + ((size_t)tap * Cin + ci0) * Cout + co;
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = ci0 + i < Cin ? p[(size_t)i * Cout] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += v[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) part[ty][i][tx] = acc[i];
+  __syncthreads();
+  const int ci = ci0 + ty;   // thread row ty now finishes input channel ci0 + ty
+  if (co < Cout_true && ci < Cin_true) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += part[r][ty][tx];
+    Elem<TD>::store(dw + co * s_co + ci * s_ci + tap * s_tap, t);
+  }
+}
+
 }  // namespace segk
 
 using namespace segk;
@@ -230,8 +270,19 @@ extern "C" int segk_wgrad_finish_strided(const float* slabs, int splits, int R, 
                "wgrad_finish: bad shape splits=%d R=%d Cin=%d Cout=%d (%d,%d)", splits, R, Cin, Cout, Cout_true,
                Cin_true);
   SEGK_REQUIRE(s_co > 0 && s_ci > 0 && s_tap > 0, "wgrad_finish: strides must be positive");
-  dim3 grid(ceil_div(Cout, 32), ceil_div(Cin, 32), R * R);
   hipStream_t st = (hipStream_t)stream;
+  if (splits >= 32 && (long long)R * R * Cin * Cout <= (1ll << 18)) {
+    dim3 tgrid(ceil_div(Cout, 32), ceil_div(Cin, 8), R * R);
+    if (dw_dtype == SEGK_BF16)
+      wgrad_finish_tree_kernel<bf16_t><<<tgrid, 256, 0, st>>>(slabs, splits, R * R, Cin, Cout, (bf16_t*)dw, s_co, s_ci,
+                                                             s_tap, Cout_true, Cin_true);
+    else
+      wgrad_finish_tree_kernel<float><<<tgrid, 256, 0, st>>>(slabs, splits, R * R, Cin, Cout, (float*)dw, s_co, s_ci,
+                                                            s_tap, Cout_true, Cin_true);
+    SEGK_CHECK_LAUNCH("wgrad_finish");
+    return SEGK_OK;
+  }
+  dim3 grid(ceil_div(Cout, 32), ceil_div(Cin, 32), R * R);
   if (dw_dtype == SEGK_BF16)
     wgrad_finish_kernel<bf16_t><<<grid, 256, 0, st>>>(slabs, splits, R * R, Cin, Cout, (bf16_t*)dw, s_co, s_ci, s_tap,
                                                       Cout_true, Cin_true);

@@ -3,7 +3,7 @@ import contextlib
 
 import torch
 
-_state = {"compute_dtype": torch.float32, "legacy_clamp_eps": False, "feeder_conv": "auto"}
+_state = {"compute_dtype": torch.float32, "legacy_clamp_eps": False, "feeder_conv": "auto", "overlap_wgrad": False}
 
 
 def set_compute_dtype(dtype):
@@ -65,3 +65,28 @@ def feeder_conv_as(mode):
         yield
     finally:
         _state["feeder_conv"] = old
+
+
+def set_overlap_wgrad(flag):
+    """True: inside ``loss.backward()`` the weight gradients of the HIP convolution units run on a second HIP stream
+    beside the chain of data gradients and batch-norm backward passes (nothing but the optimizer waits for a weight
+    gradient; a matrix-bound launch beside memory-bound ones fills the chip better than either alone).  The
+    gradients are then written to ``weight.grad`` by an end-of-backward callback after the streams have joined,
+    not returned through autograd: use it with ``.backward()`` loops only (``torch.autograd.grad`` would see None
+    for those weights, and hooks on the weights do not fire).  Ignored while gradients are exchanged between ranks:
+    the bucketed all-reduce hangs on parameter hooks.  Default False."""
+    _state["overlap_wgrad"] = bool(flag)
+
+
+def overlap_wgrad():
+    return _state["overlap_wgrad"]
+
+
+@contextlib.contextmanager
+def overlap_wgrad_as(flag):
+    old = _state["overlap_wgrad"]
+    set_overlap_wgrad(flag)
+    try:
+        yield
+    finally:
+        _state["overlap_wgrad"] = old

@@ -187,6 +187,54 @@ def unit_finish(x, raw, stats, weight, R, dil, geom, spec, gamma, beta, out, rel
     return rec
 
 
+# ---- weight gradients beside the data-gradient chain (config.set_overlap_wgrad) -------------------------------
+_SIDE_STREAMS = {}   # device index -> the second stream
+_PENDING = []        # (weight, dW, main stream, side stream, tensors the side stream reads) of the running backward
+
+
+def _join_weight_grads():
+    """End-of-backward callback: the launching stream waits for the second one, then every deferred gradient is
+    stored where autograd's accumulation node would have put it."""
+    pending = list(_PENDING)
+    del _PENDING[:]
+    joined = set()
+    for weight, dw, main, side, _ in pending:
+        if (main, side) not in joined:
+            main.wait_stream(side)
+            joined.add((main, side))
+    for weight, dw, main, side, _ in pending:
+        with torch.cuda.stream(main), torch.no_grad():
+            if weight.grad is None:
+                weight.grad = dw
+            else:
+                weight.grad.add_(dw)
+
+
+def weight_grad(weight, x, dy, N, H, W, R, dil, Cout, Cin, like=None):
+    """dW of one convolution.  Returns the gradient, or None when it was started on the second stream and will be
+    stored in weight.grad at the end of the running backward pass (config.overlap_wgrad)."""
+    deferred = (config.overlap_wgrad() and not parallel.is_distributed() and isinstance(weight, torch.Tensor)
+                and weight.is_leaf and weight.requires_grad and x.is_cuda)
+    if not deferred:
+        return ops.conv_wgrad(x, dy, N, H, W, R, dil, Cout, Cin, like=like)
+    main = torch.cuda.current_stream(x.device)
+    side = _SIDE_STREAMS.get(x.device.index)
+    if side is None:
+        side = _SIDE_STREAMS[x.device.index] = torch.cuda.Stream(device=x.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        dw = ops.conv_wgrad(x, dy, N, H, W, R, dil, Cout, Cin, like=like)
+        if like is None and (dw.dtype != weight.dtype or dw.stride() != weight.stride()):
+            dw = torch.empty_like(weight).copy_(dw)   # what autograd would have done on accumulation
+    # one callback per deferred gradient: the first to run joins and stores them all, the others find nothing left
+    # (a callback queued only "when the list was empty" would be lost for good after a backward pass that raised)
+    torch.autograd.Variable._execution_engine.queue_callback(_join_weight_grads)
+    # x and dy stay referenced until the join, so the allocator cannot hand their memory to later launches of the
+    # main stream while the second stream still reads them
+    _PENDING.append((weight, dw, main, side, (x, dy)))
+    return None
+
+
 def unit_backward(rec, dz, need_dw=True, dw_like=None):
     """dz: pixel-major gradient w.r.t. the unit's output.  Returns (dy [M, Cout rounded up to 32] with zero
     padding = gradient w.r.t. the conv output, dW, dgamma, dbeta).  dw_like: a weight whose dtype and strides dW
@@ -206,8 +254,8 @@ def unit_backward(rec, dz, need_dw=True, dw_like=None):
     dw = None
     if need_dw:
         c16 = ops.round_up(C, 16)
-        dw = ops.conv_wgrad(rec.x, dy[:, :c16] if c16 != cpad else dy, N, H, W, rec.R, rec.dil, C, rec.Cin,
-                            like=dw_like)
+        dw = weight_grad(rec.weight, rec.x, dy[:, :c16] if c16 != cpad else dy, N, H, W, rec.R, rec.dil, C, rec.Cin,
+                         like=dw_like)
     return dy, dw, dgamma, dbeta
 
 
@@ -406,7 +454,7 @@ class DecoderFunction(torch.autograd.Function):
         else:
             ops.nchw_to_pm(gout.float().contiguous(), dyc[:, :K])
         Pb = recB.Cout
-        dw8 = ops.conv_wgrad(ctx.a2p, dyc, N, H, W, 1, 1, K, Pb)
+        dw8 = weight_grad(ctx.wcls, ctx.a2p, dyc, N, H, W, 1, 1, K, Pb)
         db8 = ops.bn_local_sums(dyc, PM)[:K].float() if ctx.has_bias else None
         da2 = dgrad([(dyc, ctx.wcls, 1, 1)], ctx.geom, Pb, cd)
         dyB, dwB, dgB, dbB = unit_backward(recB, da2)

@@ -258,9 +258,13 @@ def wgrad_plan(M, Cin, Cout, R, dtype):
     chunks = max(1, (M + bp - 1) // bp)
     big = Cin >= 256 and Cout % 256 == 0 and (Cin % 256 == 0 or Cin % 256 > 128)
 
+    # a gradient of at most 256 K elements (a 1 MB slab) may be cut into SPLIT_CAP_SMALL parts: its slabs stay
+    # small and segk_wgrad_finish sums them with eight loads in flight per thread
+    cap = SPLIT_CAP_SMALL if R * R * Cin * Cout <= (1 << 18) else SPLIT_CAP
+
     def parts(t, target):
         tiles = ((Cin + t - 1) // t) * ((Cout + t - 1) // t) * R * R
-        return max(1, min(target // tiles if tiles <= target else 1, SPLIT_CAP, chunks // 8 if chunks >= 8 else 1))
+        return max(1, min(target // tiles if tiles <= target else 1, cap, chunks // 8 if chunks >= 8 else 1))
     small_target = 768 if dtype == torch.bfloat16 else 1024
     if big:
         sp = parts(256, 256)
@@ -273,6 +277,7 @@ def wgrad_plan(M, Cin, Cout, R, dtype):
 
 
 SPLIT_CAP = 64
+SPLIT_CAP_SMALL = 384
 SLAB_BUDGET = 32 << 20
 
 

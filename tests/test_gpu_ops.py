@@ -187,6 +187,27 @@ def test_conv_wgrad_exact_integers(ops, case, dtype, splits):
     assert torch.equal(got, gw)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("splits", [32, 53])
+def test_conv_wgrad_many_parts_small_gradient(ops, dtype, splits):
+    """A small gradient (1x1 onto 21 channels, as the classifier's) cut into many parts: the slabs are summed by the
+    tree form of segk_wgrad_finish (eight thread rows, every eighth part each); integers make any order exact.
+    53 parts: thread rows with different numbers of parts; 40 input channels: a last ci group that is half empty."""
+    N, H, W, Cin, Cout, R, dil = 2, 47, 41, 40, 21, 1, 1
+    x = T(gen.integers(8, "wgm_x", (N, Cin, H, W), -3, 4).astype(np.float32))
+    w = torch.zeros((Cout, Cin, 1, 1), device=DEV, requires_grad=True)
+    y = F.conv2d(x, w)
+    gy = T(gen.integers(8, "wgm_g", tuple(y.shape), -2, 3).astype(np.float32))
+    (gw,) = torch.autograd.grad(y, w, gy)
+    _, xfull = to_pm(x, dtype, ld=ops.round_up(Cin, 32))
+    _, gfull = to_pm(gy, dtype, ld=ops.round_up(Cout, 16))
+    got = ops.conv_wgrad(xfull, gfull, N, H, W, R, dil, Cout, Cin, splits=splits)
+    assert torch.equal(got, gw)
+    like = torch.empty((Cout, Cin, 1, 1), dtype=torch.bfloat16, device=DEV).to(memory_format=torch.channels_last)
+    got16 = ops.conv_wgrad(xfull, gfull, N, H, W, R, dil, Cout, Cin, splits=splits, like=like)
+    assert got16.dtype == torch.bfloat16 and torch.equal(got16.float(), gw.to(torch.bfloat16).float())
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
 def test_conv_wgrad_random_padded_input(ops, dtype, tol):
     """Decoder shape in miniature: 304 real input channels inside a 320-wide buffer."""
