@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="record the training iteration once as a HIP graph and replay it (auto: with one rank and the "
                          "HIP optimizer; ranks that exchange statistics and gradients issue their steps eagerly)")
-    ap.add_argument("--overlap-wgrad", choices=["auto", "on", "off"], default="off",
+    ap.add_argument("--overlap-wgrad", choices=["auto", "on", "off"], default="auto",
                     help="segk.config.set_overlap_wgrad: weight gradients on a second HIP stream (auto: with --graph)")
     ap.add_argument("--feeder-conv", choices=["auto", "hip", "torch"], default=None,
                     help="segk.config.set_feeder_conv: which kernels run the feeder's layer-3/4 3x3 convolutions "

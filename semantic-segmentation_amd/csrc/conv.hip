@@ -65,6 +65,8 @@ struct ConvDev {
   double* stat;
   long long m_begin;     // first pixel of this launch (a problem may be cut into a main and a tail launch)
   long long stat_row0;   // statistic partial row of this launch's first pixel tile
+  int abl;               // timing experiments of the LDS-DMA tile (experiment builds only; results are garbage):
+                         // 7 = no K loop (fixed cost only), 5 = no output stores, 8 = neither tap tables nor K loop
 };
 
 template <typename T>
@@ -193,6 +195,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x4 (&acc)[G::
 
   const int cpad = (p.Cout + 3) & ~3;
   if ((ABL == 5 || ABL == 6) && p.M >= 0) return;
+  if (p.abl == 5) return;
 #pragma unroll
   for (int j = 0; j < MJ; ++j) {
     const long long m = m0 + wc * (MJ * 16) + j * 16 + fr;
@@ -1165,12 +1168,15 @@ static int launch_fwd(ConvDev& d, hipStream_t st, int batch = 1, long long px_ti
 // ------------------------------------------------------------------------------------------------
 // PX = pixels per tile: 128 (wave tile 64 x 64, three workgroups per CU) or 256 (64 x 128, two per CU)
 
-template <typename TO, int PX>
-__global__ __launch_bounds__(256, PX == 128 ? 3 : 2) void conv_fwd_dma_kernel(const ConvDev p) {
+// STAGES = 2 (experiment builds only): two LDS stages, the loads of step k+1 are in flight under the MFMAs of step k
+// and one barrier per step remains; 64 KB of LDS, two workgroups per CU.
+template <typename TO, int PX, int STAGES = 1>
+__global__ __launch_bounds__(256, (PX == 128 && STAGES == 1) ? 3 : 2) void conv_fwd_dma_kernel(const ConvDev p) {
   typedef TileCfg<128, PX, 2, 2> G;
   constexpr int BKB = 128, MI = G::MI, MJ = G::MJ;
   constexpr int NB = PX / 32;   // activation pieces per wavefront
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [A 128 rows][B 128 rows] x 128 B, swizzled
+  constexpr int STAGE_B = (128 + PX) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // STAGES x ([A 128 rows][B PX rows] x 128 B, swizzled)
   __shared__ int taps_l[SEGK_MAX_SEG * 9];
   __shared__ int ntaps_l[SEGK_MAX_SEG];
   __shared__ unsigned int mask_l[2];
@@ -1246,6 +1252,7 @@ __global__ __launch_bounds__(256, PX == 128 ? 3 : 2) void conv_fwd_dma_kernel(co
   __syncthreads();
   int total = 0;
   for (int sg = 0; sg < p.nseg; ++sg) total += ntaps_l[sg] * (p.seg[sg].ck_b / BKB);
+  if (p.abl == 7 || p.abl == 8) total = 0;
 
   f32x4 acc[MI][MJ];
 #pragma unroll
@@ -1302,41 +1309,71 @@ __global__ __launch_bounds__(256, PX == 128 ? 3 : 2) void conv_fwd_dma_kernel(co
 
     setup_seg();
     setup_tap();
-    for (int st = 0; st < total; ++st) {
+    auto issue = [&](int stage) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) glds16(abase + aoff[i], sa_w + i * 4096);
+      for (int i = 0; i < 4; ++i) glds16(abase + aoff[i], sa_w + stage * STAGE_B + i * 4096);
 #pragma unroll
-      for (int i = 0; i < NB; ++i) glds16(bok[i] ? bbase + boff[i] : zsrc, sb_w + i * 4096);
-      if (st + 1 < total) advance();   // address arithmetic of the next step under the loads
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      for (int i = 0; i < NB; ++i) glds16(bok[i] ? bbase + boff[i] : zsrc, sb_w + stage * STAGE_B + i * 4096);
+    };
+    auto multiply = [&](int stage) {
+      const char* a = sa + stage * STAGE_B;
+      const char* b = sb + stage * STAGE_B;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         u32x4 fb[MJ];
 #pragma unroll
         for (int j = 0; j < MJ; ++j)
-          fb[j] = *reinterpret_cast<const u32x4*>(sb + tile_off<BKB>(wc * (MJ * 16) + j * 16 + frow, ks * 4 + fg));
+          fb[j] = *reinterpret_cast<const u32x4*>(b + tile_off<BKB>(wc * (MJ * 16) + j * 16 + frow, ks * 4 + fg));
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-          const u32x4 fa = *reinterpret_cast<const u32x4*>(sa + tile_off<BKB>(wr * (MI * 16) + i * 16 + frow, ks * 4 + fg));
+          const u32x4 fa = *reinterpret_cast<const u32x4*>(a + tile_off<BKB>(wr * (MI * 16) + i * 16 + frow, ks * 4 + fg));
 #pragma unroll
           for (int j = 0; j < MJ; ++j) Mma<bf16_t>::run(fa, fb[j], acc[i][j]);
         }
       }
-      __syncthreads();
+    };
+    if (STAGES == 1) {
+      for (int st = 0; st < total; ++st) {
+        issue(0);
+        if (st + 1 < total) advance();   // address arithmetic of the next step under the loads
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        multiply(0);
+        __syncthreads();
+      }
+    } else {
+      issue(0);
+      for (int st = 0; st < total; ++st) {
+        const bool more = st + 1 < total;
+        if (more) advance();             // addresses of step st+1 while the loads of step st are in flight
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                 // step st has landed for everyone; everyone is done reading step st-1
+        if (more) issue((st + 1) & 1);   // ... whose stage these loads overwrite, under the MFMAs below
+        multiply(st & 1);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                   // the epilogue reuses the LDS
     }
   }
 
   conv_epilogue<TO, G>(p, acc, smem, wr, wc, lane, tid, co0, m0, mt, bz);
 }
 
+static int cu_count() {
+  static int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    return v;
+  }();
+  return n;
+}
+
 // px_tiles < 0: every pixel tile from d.m_begin to the end
 template <typename TO, int PX = 128>
 static int launch_dma(ConvDev& d, hipStream_t st, int batch = 1, long long px_tiles = -1) {
   constexpr int lds = (128 + PX) * 128;
-  static LdsConfigured configured;  // per instantiation
-  int rc = set_lds(conv_fwd_dma_kernel<TO, PX>, lds, "conv_fwd_dma", configured);
-  if (rc != SEGK_OK) return rc;
   d.n_tiles = ceil_div(d.Cout, 128);
   if (px_tiles < 0) px_tiles = (d.M - d.m_begin + PX - 1) / PX;
   const long long blocks = px_tiles * d.n_tiles;
@@ -1344,6 +1381,22 @@ static int launch_dma(ConvDev& d, hipStream_t st, int batch = 1, long long px_ti
     set_error("conv: too many tiles");
     return SEGK_INVALID_ARG;
   }
+#ifdef SEGK_EXPERIMENTS
+  // SEGK_CONV_STAGES=2: the two-stage form of the 128 x 128 tile.  Measured (rocprofv3 kernel durations): level with
+  // the one-stage form on launches of one workgroup per CU (55.4 us both on the 274-tile 3x3 of ResNet layer 3) and
+  // 25-45 % slower on larger ones (two workgroups per CU instead of three), so it is not a default anywhere.
+  static const char* stages = experiment("SEGK_CONV_STAGES");
+  if (PX == 128 && stages && stages[0] == '2') {
+    static LdsConfigured configured2;  // per instantiation
+    int rc = set_lds(conv_fwd_dma_kernel<TO, 128, 2>, 2 * 256 * 128, "conv_fwd_dma (two stages)", configured2);
+    if (rc != SEGK_OK) return rc;
+    conv_fwd_dma_kernel<TO, 128, 2><<<dim3((unsigned)blocks, (unsigned)batch), 256, 2 * 256 * 128, st>>>(d);
+    return SEGK_OK;
+  }
+#endif
+  static LdsConfigured configured;  // per instantiation
+  int rc = set_lds(conv_fwd_dma_kernel<TO, PX>, lds, "conv_fwd_dma", configured);
+  if (rc != SEGK_OK) return rc;
   conv_fwd_dma_kernel<TO, PX><<<dim3((unsigned)blocks, (unsigned)batch), 256, lds, st>>>(d);
   return SEGK_OK;
 }
@@ -1382,17 +1435,6 @@ static int launch_pipe(ConvDev& d, hipStream_t st, int batch = 1) {
 static bool use_pipe() {
   static const char* e = experiment("SEGK_CONV_PIPE");
   return e && e[0] == '1';
-}
-
-static int cu_count() {
-  static int n = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-      v = 256;
-    return v;
-  }();
-  return n;
 }
 
 // Rows of statistic partials = pixel tiles of the geometry chosen for this problem.
@@ -1488,6 +1530,10 @@ static bool fill_dev(const segk_conv_args* a, ConvDev& d) {
   d.M = (long long)a->N * d.HW;
   d.Cout = a->Cout; d.nseg = a->nseg;
   d.n_tiles = 0;
+  {
+    static const char* abl = experiment("SEGK_DMA_ABL");
+    d.abl = abl ? atoi(abl) : 0;
+  }
   const int es = dtype_size(a->dtype);
   bool wide = true;
   for (int s = 0; s < SEGK_MAX_SEG; ++s) {
@@ -1659,6 +1705,7 @@ extern "C" int segk_gemm_nt(const segk_gemm_args* a, segk_stream_t stream) {
   ConvDev d;
   d.H = 1; d.W = a->M; d.HW = a->M; d.M = a->M;
   d.Cout = a->N; d.nseg = a->nterms; d.n_tiles = 0;
+  d.abl = 0;
   bool wide = true;
   for (int s = 0; s < SEGK_MAX_SEG; ++s) {
     const segk_gemm_term& t = a->term[s < a->nterms ? s : 0];

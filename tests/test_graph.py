@@ -157,3 +157,30 @@ def test_refuses_other_shapes_and_frozen_rates():
     opt.param_groups[0]["lr"] = 0.05
     with pytest.raises(RuntimeError, match="learning rate changed"):
         stepper(x, y)
+
+
+def test_weight_gradients_on_second_stream_equal_inline(deterministic_feeder):
+    """config.set_overlap_wgrad: the head's weight gradients run on a second stream and reach weight.grad through the
+    end-of-backward callback.  Same kernels, same operands: every gradient equals the inline path bit for bit, also
+    when a second backward pass accumulates into existing gradients."""
+    from segk import config
+    from segk.utils.loss import SegmentationLosses
+    dev = "cuda:0"
+    config.set_compute_dtype(torch.float32)
+    g = torch.Generator().manual_seed(9)
+    image = torch.randn(2, 3, 65, 65, generator=g).to(dev)
+    target = torch.randint(0, 6, (2, 65, 65), generator=g).float().to(dev)
+    crit = SegmentationLosses(weight=None, cuda=True).build_loss("ce")
+
+    def grads(overlap):
+        model = _small_model(21)
+        with config.feeder_conv_as("torch"), config.overlap_wgrad_as(overlap):
+            for _ in range(2):   # the second pass adds to the first one's gradients
+                crit(model(image), target).backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+
+    inline, overlapped = grads(False), grads(True)
+    assert inline.keys() == overlapped.keys()
+    for n in inline:
+        assert torch.equal(inline[n], overlapped[n]), n

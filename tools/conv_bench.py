@@ -41,7 +41,13 @@ def main():
            ("dec 3x3 304", 129, 304, 320, 256, 3, 1), ("dec 3x3 256", 129, 256, 256, 256, 3, 1),
            ("dec cls 1x1", 129, 256, 256, 21, 1, 1),
            ("dgrad dec 3x3 256", 129, 256, 256, 256, 3, 1), ("dgrad dec 3x3 304", 129, 256, 256, 304, 3, 1),
-           ("dgrad proj", 33, 256, 256, 1280, 1, 1)]
+           ("dgrad proj", 33, 256, 256, 1280, 1, 1),
+           # the feeder's stride-1 bottleneck 3x3s (ResNet layers 3 and 4 at output stride 16)
+           ("feeder l3 3x3", 33, 256, 256, 256, 3, 1), ("feeder l4 3x3 d2", 33, 512, 512, 512, 3, 2),
+           ("feeder l4 3x3 d4", 33, 512, 512, 512, 3, 4),
+           # same map and output width, growing K: the slope is the cost of a K step, the intercept the fixed part
+           ("probe k 3x3 c64", 33, 64, 64, 256, 3, 1), ("probe k 3x3 c128", 33, 128, 128, 256, 3, 1),
+           ("probe k 3x3 c512", 33, 512, 512, 256, 3, 1), ("probe k 3x3 c1024", 33, 1024, 1024, 256, 3, 1)]
     for name, H, cin, cpad, cout, R, dil in fwd:
         if args.only and args.only not in name:
             continue
@@ -50,7 +56,7 @@ def main():
         w = torch.randn((cout, cin, R, R), device=dev) * 0.05
         wp = ops.pack_weight(w, dt)
         out = torch.empty((M, ops.round_up(cout, 4)), dtype=dt, device=dev)
-        ms = timeit(lambda: ops.conv_fwd([(x, wp, R, dil)], n, H, H, cout, out, want_stats=True))
+        ms = timeit(lambda: ops.conv_fwd([(x, wp, R, dil)], n, H, H, cout, out, want_stats=not os.environ.get("CONV_BENCH_NOSTATS")))
         fl = 2.0 * M * cout * cin * R * R
         print("fwd   %-20s M=%7d  %8.1f us  %7.1f TF nominal" % (name, M, ms * 1e3, fl / ms / 1e9))
     if not args.only or "asppdgrad" in args.only:
