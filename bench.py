@@ -399,6 +399,7 @@ def main():
             # issued eagerly with HIP events around every convolution call, right behind the timed region
             timer = ops.KernelTimer()
             ops.TIMER = timer
+            config.set_overlap_wgrad(False)   # one launch at a time on the chip: durations of overlapped launches mean nothing
             for i in range(steps):
                 step(warmup + steps + i)
             torch.cuda.synchronize()
@@ -446,8 +447,8 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                "traffic": None,
                                "kernel": "conv_fwd_dma_kernel / conv_fwd_kernel (implicit-GEMM forward + data "
-                               "gradient, all %d segk_conv_fwd calls of the timed steps, each bracketed by two HIP events on "
-                               "the launch stream; a call is one launch or a main + tail pair)" % dom["launches"],
+                               "gradient, all %d segk_conv_fwd calls of the head in the timed steps, each bracketed by two HIP events "
+                               "on the launch stream; a call is one launch or a main + tail pair)" % dom["launches"],
                                "avg_launch_ms": dom["avg_ms"], "share_of_step": dom["ms"] / (1000.0 * elapsed)}
         wg = res["conv"].get("conv_wgrad_kernel")
         if wg:
@@ -455,9 +456,22 @@ def main():
             out["roofline_wgrad"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                      "avg_launch_ms": wg["avg_ms"],
                                      "kernel": "conv_wgrad_kernel / conv_wgrad_dma_kernel + wgrad_finish_kernel (%d "
-                                               "weight gradients: the split-slab launch and the fixed-order slab sum "
-                                               "inside one bracket)" % wg["launches"],
+                                               "weight gradients of the head: the split-slab launch and the fixed-order "
+                                               "slab sum inside one bracket)" % wg["launches"],
                                      "share_of_step": wg["ms"] / (1000.0 * elapsed)}
+        # the feeder's 3x3 bottleneck convolutions, when they run on the same kernels (segk.config.feeder_conv):
+        # 33 x 33 maps, 274 or 548 workgroups per launch - a population of its own, kept apart from the head's
+        fd, fw = res["conv"].get("conv_fwd_kernel@feeder"), res["conv"].get("conv_wgrad_kernel@feeder")
+        if fd and fw:
+            a1, a2 = fd["flops"] / (fd["ms"] * 1e-3) / 1e12, fw["flops"] / (fw["ms"] * 1e-3) / 1e12
+            out["roofline_feeder_convs"] = {
+                "bound": "mfma", "peak": peak, "unit": "TFLOP/s",
+                "fwd_dgrad": {"achieved": a1, "frac": a1 / peak, "launches": fd["launches"], "avg_launch_ms": fd["avg_ms"],
+                              "share_of_step": fd["ms"] / (1000.0 * elapsed)},
+                "wgrad": {"achieved": a2, "frac": a2 / peak, "launches": fw["launches"], "avg_launch_ms": fw["avg_ms"],
+                          "share_of_step": fw["ms"] / (1000.0 * elapsed)},
+                "kernel": "the same kernels on the 25 stride-1 3x3 bottleneck convolutions of ResNet layers 3 and 4 "
+                          "(M = 17 424 pixels, 256 or 512 channels): small launches, a third of their time is fixed cost"}
         return out
 
     main_res = measure(args.dtype, args.steps, args.warmup, not args.no_kernel_timing)
@@ -499,7 +513,8 @@ def main():
                 calls = main_res["conv"]["conv_fwd_kernel"]["launches"] / float(args.steps)
                 line["roofline"]["traffic"] = measured_traffic(args, ("conv_fwd_dma_kernel", "conv_fwd_kernel"), calls)
                 line["roofline"]["traffic_unit"] = ("HBM bytes per segk_conv_fwd call (rocprofv3 FETCH_SIZE x2 + "
-                                                    "WRITE_SIZE, profiles/pmc_traffic.json)")
+                                                    "WRITE_SIZE, profiles/pmc_traffic.json: counter passes with the feeder on MIOpen, "
+                                                    "so that only the head's launches are counted)")
             summ = main_res["hbm"]
             step_ms = 1000.0 * elapsed / args.steps
             bn = [v for k, v in summ.items() if k.startswith("bn_")]

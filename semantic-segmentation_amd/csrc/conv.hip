@@ -876,25 +876,47 @@ __global__ __launch_bounds__(CONV_THREADS * NSUB, NSUB == 1 ? 2 : 1) void conv_w
   // wavefronts whose input or output channels lie entirely beyond the tensor (partial last tile) skip the MFMA work
   const bool wave_live = ci0 + wc * 64 < p.Cin && co0 + wr * (MI * 16) < p.Cout;
   u32x4 rd[NP], rx[NP];
-  // load chunk `ck`; returns whether any of this thread's shifted rows is inside the image
-  auto load_chunk = [&](int ck) -> int {
+  // per loader row: pixel index, (y, x) and source addresses, advanced by one chunk per call with additions and a
+  // wrap test (a division pair and two 64-bit multiplications per row and chunk would cost as much as the MFMAs)
+  long long mrow[NP];
+  int my[NP], mx[NP];
+  const char* dptr[NP];
+  const char* xptr[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    mrow[i] = pbeg + lr + i * RPP;
+    const int rem = pixel_in_image(mrow[i] < p.M ? mrow[i] : 0, p.HW);
+    my[i] = rem / p.W;
+    mx[i] = rem - my[i] * p.W;
+    dptr[i] = dbase + mrow[i] * p.dout_ld_b;
+    xptr[i] = xbase + (mrow[i] + (long long)dy * p.W + dx) * p.in_ld_b;
+  }
+  const int step_y = BP / p.W, step_x = BP - step_y * p.W;
+  const long long dstep = (long long)BP * p.dout_ld_b, xstep = (long long)BP * p.in_ld_b;
+  // load the next chunk (chunks are taken in order); returns whether any of this thread's shifted rows is inside
+  // the image
+  auto load_chunk = [&](int) -> int {
     int any = 0;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const long long m = pbeg + (long long)ck * BP + lr + i * RPP;
       u32x4 z = {0u, 0u, 0u, 0u};
       rd[i] = z;
       rx[i] = z;
-      if (m < pend) {
-        const int rem = pixel_in_image(m, p.HW);
-        const int y = rem / p.W, x = rem - y * p.W;
-        const bool in_img = (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W;
-        if (in_img) {
-          any = 1;
-          if (d_ok) rd[i] = *reinterpret_cast<const u32x4*>(dbase + m * p.dout_ld_b);
-          if (x_ok) rx[i] = *reinterpret_cast<const u32x4*>(xbase + (m + (long long)dy * p.W + dx) * p.in_ld_b);
-        }
+      if (mrow[i] < pend && (unsigned)(my[i] + dy) < (unsigned)p.H && (unsigned)(mx[i] + dx) < (unsigned)p.W) {
+        any = 1;
+        if (d_ok) rd[i] = *reinterpret_cast<const u32x4*>(dptr[i]);
+        if (x_ok) rx[i] = *reinterpret_cast<const u32x4*>(xptr[i]);
       }
+      mrow[i] += BP;
+      dptr[i] += dstep;
+      xptr[i] += xstep;
+      mx[i] += step_x;
+      my[i] += step_y;
+      if (mx[i] >= p.W) {
+        mx[i] -= p.W;
+        ++my[i];
+      }
+      while (my[i] >= p.H) my[i] -= p.H;   // next image (several at once only for images smaller than a chunk)
     }
     return any;
   };
@@ -1013,24 +1035,51 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_dma_kernel(const WgradDev p
   char* const sd_w = smem + wave * 1024;            // + i * 4096
   char* const sx_w = smem + SUB_B + wave * 1024;
 
+  // Per loader row: pixel index, its (y, x) and the two source addresses, advanced by one chunk (BP pixels) per trip
+  // with additions and one wrap test - a division pair and two 64-bit multiplications per row and chunk cost more
+  // issue slots than the chunk's MFMAs.
+  long long mrow[4];
+  int my[4], mx[4];
+  const char* dptr[4];
+  const char* xptr[4];
+  bool dcol[4], xcol[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    mrow[i] = pbeg + lrow[i];
+    const int rem = pixel_in_image(mrow[i] < p.M ? mrow[i] : 0, p.HW);
+    my[i] = rem / p.W;
+    mx[i] = rem - my[i] * p.W;
+    dcol[i] = co0 + csrc[i] * 8 < p.Cout;
+    xcol[i] = ci0 + csrc[i] * 8 < p.Cin;
+    dptr[i] = dbase + mrow[i] * p.dout_ld_b + csrc[i] * 16;
+    xptr[i] = xbase + (mrow[i] + (long long)dy * p.W + dx) * p.in_ld_b + csrc[i] * 16;
+  }
+  const int step_y = BP / p.W, step_x = BP - step_y * p.W;
+  const long long dstep = (long long)BP * p.dout_ld_b, xstep = (long long)BP * p.in_ld_b;
+
   for (int ck = 0; ck < nchunks; ++ck) {
     int any = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const long long m = pbeg + (long long)ck * BP + lrow[i];
       const char* ds = zsrc;
       const char* xs = zsrc;
-      if (m < pend) {
-        const int rem = pixel_in_image(m, p.HW);
-        const int y = rem / p.W, x = rem - y * p.W;
-        if ((unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W) {
-          any = 1;
-          if (co0 + csrc[i] * 8 < p.Cout) ds = dbase + m * p.dout_ld_b + csrc[i] * 16;
-          if (ci0 + csrc[i] * 8 < p.Cin) xs = xbase + (m + (long long)dy * p.W + dx) * p.in_ld_b + csrc[i] * 16;
-        }
+      if (mrow[i] < pend && (unsigned)(my[i] + dy) < (unsigned)p.H && (unsigned)(mx[i] + dx) < (unsigned)p.W) {
+        any = 1;
+        if (dcol[i]) ds = dptr[i];
+        if (xcol[i]) xs = xptr[i];
       }
       glds16(ds, sd_w + i * 4096);
       glds16(xs, sx_w + i * 4096);
+      mrow[i] += BP;
+      dptr[i] += dstep;
+      xptr[i] += xstep;
+      mx[i] += step_x;
+      my[i] += step_y;
+      if (mx[i] >= p.W) {
+        mx[i] -= p.W;
+        ++my[i];
+      }
+      while (my[i] >= p.H) my[i] -= p.H;   // next image (several at once only for images smaller than a chunk)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int cur_any = __syncthreads_or(any);
@@ -1170,18 +1219,34 @@ static int launch_fwd(ConvDev& d, hipStream_t st, int batch = 1, long long px_ti
 
 // STAGES = 2 (experiment builds only): two LDS stages, the loads of step k+1 are in flight under the MFMAs of step k
 // and one barrier per step remains; 64 KB of LDS, two workgroups per CU.
+// STAGES = 3: the two-stage tile with SPECIALISED wavefronts, 512 threads: wavefronts 0-3 only issue the LDS-DMA of
+// step k+1 (an issuing wavefront is held ~120 cycles per 1-KiB global_load_lds, so it cannot put its own loads under
+// its own MFMAs), wavefronts 4-7 only read fragments and issue the MFMAs of step k; one barrier per step joins them.
+// For launches of at most two workgroups per CU (the 274-tile convolutions on 33 x 33 maps), where no other workgroup
+// is there to multiply while one loads.
 template <typename TO, int PX, int STAGES = 1>
-__global__ __launch_bounds__(256, (PX == 128 && STAGES == 1) ? 3 : 2) void conv_fwd_dma_kernel(const ConvDev p) {
+__global__ __launch_bounds__(STAGES == 3 ? 512 : 256, (PX == 128 && STAGES == 1) ? 3 : 2) void conv_fwd_dma_kernel(const ConvDev p) {
   typedef TileCfg<128, PX, 2, 2> G;
   constexpr int BKB = 128, MI = G::MI, MJ = G::MJ;
   constexpr int NB = PX / 32;   // activation pieces per wavefront
   constexpr int STAGE_B = (128 + PX) * 128;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // STAGES x ([A 128 rows][B PX rows] x 128 B, swizzled)
+  constexpr bool SPEC = STAGES == 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // stages x ([A 128 rows][B PX rows] x 128 B, swizzled)
   __shared__ int taps_l[SEGK_MAX_SEG * 9];
   __shared__ int ntaps_l[SEGK_MAX_SEG];
   __shared__ unsigned int mask_l[2];
+  // per listed tap, filled once: byte offsets of its weight slice and of its shifted pixel window, and the shift
+  // itself - the K loop then needs two table reads and two additions per step instead of two divisions, a run of
+  // 64-bit multiplications and a dynamically indexed read of the segment descriptor
+  __shared__ long long tap_a_l[SEGK_MAX_SEG * 9];
+  __shared__ long long tap_b_l[SEGK_MAX_SEG * 9];
+  __shared__ int tap_dy_l[SEGK_MAX_SEG * 9];
+  __shared__ int tap_dx_l[SEGK_MAX_SEG * 9];
 
-  const int tid = threadIdx.x;
+  // specialised form: threads 0-255 load (and own the tile-row geometry below), threads 256-511 multiply
+  const bool loader = !SPEC || threadIdx.x < 256;
+  const bool multiplier = !SPEC || threadIdx.x >= 256;
+  const int tid = SPEC ? (int)(threadIdx.x & 255) : (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave / G::WPX, wc = wave % G::WPX;
   // Workgroups go to the eight XCDs round-robin by block index; give each XCD a contiguous run of tiles, so that
@@ -1219,9 +1284,9 @@ __global__ __launch_bounds__(256, (PX == 128 && STAGES == 1) ? 3 : 2) void conv_
     rx[i] = rem - ry[i] * p.W;
   }
 
-  if (tid < 2) mask_l[tid] = 0u;
+  if (threadIdx.x < 2) mask_l[threadIdx.x] = 0u;
   __syncthreads();
-  {
+  if (loader) {
     unsigned long long mine = 0ull;
     for (int sg = 0; sg < p.nseg; ++sg) {
       const int R = p.seg[sg].R, dil = p.seg[sg].dil + (int)blockIdx.y * p.dil_step;
@@ -1239,14 +1304,25 @@ __global__ __launch_bounds__(256, (PX == 128 && STAGES == 1) ? 3 : 2) void conv_
     if (hi) atomicOr(&mask_l[1], hi);
   }
   __syncthreads();
-  if (tid == 0) {
+  if (threadIdx.x < SEGK_MAX_SEG * 9) {
+    // thread (segment, tap): a tap that touches the tile takes the list slot given by the number of listed taps
+    // before it
     const unsigned long long all = ((unsigned long long)mask_l[1] << 32) | mask_l[0];
-    for (int sg = 0; sg < p.nseg; ++sg) {
-      int cnt = 0;
-      const int R = p.seg[sg].R;
-      for (int tap = 0; tap < R * R; ++tap)
-        if ((all >> (sg * 9 + tap)) & 1ull) taps_l[sg * 9 + cnt++] = tap;
-      ntaps_l[sg] = cnt;
+    const int sg = threadIdx.x / 9, tap = threadIdx.x - sg * 9;
+    if (sg < p.nseg) {
+      const unsigned seg_bits = (unsigned)(all >> (sg * 9)) & 0x1ffu;
+      if (tap == 0) ntaps_l[sg] = __popc(seg_bits);
+      if ((seg_bits >> tap) & 1u) {
+        const SegDev& sd = p.seg[sg];
+        const int slot = sg * 9 + __popc(seg_bits & ((1u << tap) - 1u));
+        const int R = sd.R, dil = sd.dil + (int)blockIdx.y * p.dil_step;
+        const int dy = (tap / R - (R >> 1)) * dil, dx = (tap % R - (R >> 1)) * dil;
+        taps_l[slot] = tap;
+        tap_a_l[slot] = (long long)tap * sd.w_tap_b;
+        tap_b_l[slot] = ((long long)dy * p.W + dx) * sd.in_ld_b;
+        tap_dy_l[slot] = dy;
+        tap_dx_l[slot] = dx;
+      }
     }
   }
   __syncthreads();
@@ -1268,26 +1344,28 @@ __global__ __launch_bounds__(256, (PX == 128 && STAGES == 1) ? 3 : 2) void conv_
     bool bok[NB];
     const char* abase = nullptr;
     const char* bbase = nullptr;
+    const char* aseg = nullptr;   // weight rows of this tile / pixel rows of this tile in the current segment
+    const char* bseg = nullptr;
     auto setup_seg = [&]() {
       const SegDev& s = p.seg[sg];
 #pragma unroll
       for (int i = 0; i < 4; ++i) aoff[i] = (unsigned)wrow[i] * (unsigned)s.w_ld_b + lchunk;
 #pragma unroll
       for (int i = 0; i < NB; ++i) boff[i] = (unsigned)((i * 4 + wave) * 8 + lrow) * (unsigned)s.in_ld_b + lchunk;
+      aseg = s.w + bz * s.w_batch_b + (long long)co0 * s.w_ld_b;
+      bseg = s.in + bz * s.in_batch_b + m0 * s.in_ld_b;
     };
     auto setup_tap = [&]() {
-      const SegDev& s = p.seg[sg];
-      const int tap = taps_l[sg * 9 + ti];
-      const int R = s.R;
-      const int dil = s.dil + (int)bz * p.dil_step;
-      const int dy = (tap / R - (R >> 1)) * dil, dx = (tap % R - (R >> 1)) * dil;
-      abase = s.w + bz * s.w_batch_b + (long long)tap * s.w_tap_b + (long long)co0 * s.w_ld_b + (long long)kc * BKB;
-      bbase = s.in + bz * s.in_batch_b + (m0 + (long long)dy * p.W + dx) * s.in_ld_b + (long long)kc * BKB;
+      const int slot = sg * 9 + ti;
+      const int dy = tap_dy_l[slot], dx = tap_dx_l[slot];
+      abase = aseg + tap_a_l[slot] + kc * BKB;
+      bbase = bseg + tap_b_l[slot] + kc * BKB;
 #pragma unroll
       for (int i = 0; i < NB; ++i)
         bok[i] = rvalid[i] && (unsigned)(ry[i] + dy) < (unsigned)p.H && (unsigned)(rx[i] + dx) < (unsigned)p.W;
     };
     auto advance = [&]() {
+      if (p.abl == 3) return;           // timing experiment: every step loads the first step's tiles
       if (++ti >= ntaps_l[sg]) {
         ti = 0;
         if (++kc >= nkc) {
@@ -1310,12 +1388,14 @@ __global__ __launch_bounds__(256, (PX == 128 && STAGES == 1) ? 3 : 2) void conv_
     setup_seg();
     setup_tap();
     auto issue = [&](int stage) {
+      const bool fake = p.abl == 1;   // timing experiment: every load reads the zero page
 #pragma unroll
-      for (int i = 0; i < 4; ++i) glds16(abase + aoff[i], sa_w + stage * STAGE_B + i * 4096);
+      for (int i = 0; i < 4; ++i) glds16(fake ? zsrc : abase + aoff[i], sa_w + stage * STAGE_B + i * 4096);
 #pragma unroll
-      for (int i = 0; i < NB; ++i) glds16(bok[i] ? bbase + boff[i] : zsrc, sb_w + stage * STAGE_B + i * 4096);
+      for (int i = 0; i < NB; ++i) glds16(bok[i] && !fake ? bbase + boff[i] : zsrc, sb_w + stage * STAGE_B + i * 4096);
     };
     auto multiply = [&](int stage) {
+      if (p.abl == 2) return;         // timing experiment: loads and barriers only
       const char* a = sa + stage * STAGE_B;
       const char* b = sb + stage * STAGE_B;
 #pragma unroll
@@ -1341,7 +1421,7 @@ __global__ __launch_bounds__(256, (PX == 128 && STAGES == 1) ? 3 : 2) void conv_
         multiply(0);
         __syncthreads();
       }
-    } else {
+    } else if (STAGES == 2) {
       issue(0);
       for (int st = 0; st < total; ++st) {
         const bool more = st + 1 < total;
@@ -1353,9 +1433,30 @@ __global__ __launch_bounds__(256, (PX == 128 && STAGES == 1) ? 3 : 2) void conv_
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                   // the epilogue reuses the LDS
+    } else if (loader) {
+      // barrier k (k = 0 .. total-1): the loads of step k have landed, the multipliers are done with step k-1
+      issue(0);
+      for (int st = 0; st < total; ++st) {
+        const bool more = st + 1 < total;
+        if (more) advance();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (more) issue((st + 1) & 1);   // into the stage the multipliers left before this barrier
+      }
+      __syncthreads();                   // the multipliers are done with the last step (their epilogue reuses the LDS)
+    } else {
+      for (int st = 0; st < total; ++st) {
+        __syncthreads();
+        multiply(st & 1);
+      }
+      __syncthreads();
     }
   }
 
+  if (SPEC && !multiplier) {
+    if (p.stat) __syncthreads();         // the barrier inside the statistics part of the epilogue
+    return;
+  }
   conv_epilogue<TO, G>(p, acc, smem, wr, wc, lane, tid, co0, m0, mt, bz);
 }
 
@@ -1380,6 +1481,20 @@ static int launch_dma(ConvDev& d, hipStream_t st, int batch = 1, long long px_ti
   if (blocks >= 2147483647LL) {
     set_error("conv: too many tiles");
     return SEGK_INVALID_ARG;
+  }
+  {
+    // at most two workgroups per CU: the form with specialised wavefronts (SEGK_CONV_STAGES=1 in experiment builds
+    // keeps the one-stage tile for comparison)
+    static const char* st_env = experiment("SEGK_CONV_STAGES");
+    const bool want = st_env ? st_env[0] == '3' : blocks * batch <= 2LL * cu_count();
+    if (PX == 128 && want) {
+      constexpr int lds3 = 2 * 256 * 128;
+      static LdsConfigured configured3;  // per instantiation
+      int rc = set_lds(conv_fwd_dma_kernel<TO, 128, 3>, lds3, "conv_fwd_dma (specialised wavefronts)", configured3);
+      if (rc != SEGK_OK) return rc;
+      conv_fwd_dma_kernel<TO, 128, 3><<<dim3((unsigned)blocks, (unsigned)batch), 512, lds3, st>>>(d);
+      return SEGK_OK;
+    }
   }
 #ifdef SEGK_EXPERIMENTS
   // SEGK_CONV_STAGES=2: the two-stage form of the 128 x 128 tile.  Measured (rocprofv3 kernel durations): level with

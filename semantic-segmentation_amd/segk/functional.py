@@ -691,7 +691,8 @@ class ConvBNReLUFunction(torch.autograd.Function):
         w_op = weight.detach()
         if w_op.dtype != cd or not ops.weight_usable_in_place(w_op, R, Cout):   # a channels_last bf16 weight is read as it is
             w_op = ops.pack_weight(w_op, cd)
-        stats = ops.conv_fwd([(xv, w_op, R, dil)], N, H, W, Cout, raw, want_stats=spec.training, true_ck=[Cin])
+        with ops.scoped("@feeder"):
+            stats = ops.conv_fwd([(xv, w_op, R, dil)], N, H, W, Cout, raw, want_stats=spec.training, true_ck=[Cin])
         y = torch.empty((N, Cout, H, W), dtype=cd, device=x.device, memory_format=torch.channels_last)
         rec = unit_finish(xv, raw, stats, weight, R, dil, (N, H, W), spec, gamma, beta, pm_view_of(y), relu=True)
         ctx.rec, ctx.x = rec, x
@@ -703,12 +704,13 @@ class ConvBNReLUFunction(torch.autograd.Function):
     def backward(ctx, g):
         rec, x = ctx.rec, ctx.x
         N, H, W = rec.geom
-        dy, dw, dgamma, dbeta = unit_backward(rec, to_pm(g, rec.x.dtype), need_dw=ctx.needs_input_grad[1],
-                                              dw_like=rec.weight)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dxp = dgrad([(dy, rec.weight, rec.R, rec.dil)], rec.geom, rec.Cin, grad_dtype_for(x))
-            dx = grad_like(x, dxp, N, H, W)
+        with ops.scoped("@feeder"):
+            dy, dw, dgamma, dbeta = unit_backward(rec, to_pm(g, rec.x.dtype), need_dw=ctx.needs_input_grad[1],
+                                                  dw_like=rec.weight)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dxp = dgrad([(dy, rec.weight, rec.R, rec.dil)], rec.geom, rec.Cin, grad_dtype_for(x))
+                dx = grad_like(x, dxp, N, H, W)
         return dx, dw, dgamma, dbeta, None, None
 
 

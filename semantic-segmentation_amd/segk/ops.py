@@ -66,6 +66,7 @@ class KernelTimer:
     def __init__(self):
         self.records = {}   # name -> list of (flops or bytes, start_event, end_event)
         self.hbm = False    # also time the memory-bound batch-norm launches (their record holds algorithmic bytes)
+        self.scope = ""     # suffix of the record names while a caller's `scoped()` block is open
 
     def start(self):
         e = torch.cuda.Event(enable_timing=True)
@@ -75,7 +76,7 @@ class KernelTimer:
     def stop(self, name, flops, start):
         e = torch.cuda.Event(enable_timing=True)
         e.record()
-        self.records.setdefault(name, []).append((flops, start, e))
+        self.records.setdefault(name + self.scope, []).append((flops, start, e))
 
     def summary(self):
         """name -> dict(launches, flops (sum), ms (sum), avg_ms); call after torch.cuda.synchronize()."""
@@ -88,6 +89,24 @@ class KernelTimer:
 
 
 TIMER = None
+
+
+class scoped:
+    """`with ops.scoped("@feeder"):` files the launches timed inside under `<name>@feeder` (no effect without a
+    timer): bench.py keeps the head's convolutions and the feeder's apart."""
+
+    def __init__(self, suffix):
+        self.suffix = suffix
+
+    def __enter__(self):
+        self.timer = TIMER
+        if self.timer is not None:
+            self.old = self.timer.scope
+            self.timer.scope = self.suffix
+
+    def __exit__(self, *exc):
+        if self.timer is not None:
+            self.timer.scope = self.old
 
 
 def _hbm_start():
