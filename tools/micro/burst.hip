@@ -12,12 +12,14 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
 
 // PER_WAVE instructions per wavefront and burst (1 KiB each); DEPTH = 1: wait for the burst just issued;
 // DEPTH = 2: wait for the previous one while the newest is in flight
-template <int WAVES, int PER_WAVE, int DEPTH, bool BARRIER = true>
+// SWZ: the 16-byte chunk a lane fetches is XOR-ed with its row (the swizzle the convolution tiles apply through the
+// source address so that their fragment reads are bank-conflict free)
+template <int WAVES, int PER_WAVE, int DEPTH, bool BARRIER = true, bool SWZ = false>
 __global__ __launch_bounds__(WAVES * 64) void burst_kernel(const char* src, int steps, long long wg_stride_b,
                                                               int window_rows, long long* cycles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const char* base = src + (long long)blockIdx.x * wg_stride_b + (lane & 7) * 16;
+  const char* base = src + (long long)blockIdx.x * wg_stride_b + (SWZ ? ((lane & 7) ^ (lane >> 3)) : (lane & 7)) * 16;
   const int lrow = lane >> 3;
   int row = wave * 8;
   __syncthreads();
@@ -44,18 +46,18 @@ __global__ __launch_bounds__(WAVES * 64) void burst_kernel(const char* src, int 
   if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
-template <int WAVES, int PER_WAVE, int DEPTH, bool BARRIER = true>
+template <int WAVES, int PER_WAVE, int DEPTH, bool BARRIER = true, bool SWZ = false>
 static void run(const char* name, const char* buf, int grid, long long wg_stride, int wgs_per_cu_note) {
   long long* cyc;
   (void)hipMalloc(&cyc, grid * sizeof(long long));
   const int steps = 2000, lds = DEPTH * WAVES * PER_WAVE * 1024;
-  (void)hipFuncSetAttribute((const void*)burst_kernel<WAVES, PER_WAVE, DEPTH, BARRIER>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute((const void*)burst_kernel<WAVES, PER_WAVE, DEPTH, BARRIER, SWZ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
-  burst_kernel<WAVES, PER_WAVE, DEPTH, BARRIER><<<grid, WAVES * 64, lds>>>(buf, 50, wg_stride, 4096, cyc);
+  burst_kernel<WAVES, PER_WAVE, DEPTH, BARRIER, SWZ><<<grid, WAVES * 64, lds>>>(buf, 50, wg_stride, 4096, cyc);
   (void)hipEventRecord(e0);
-  burst_kernel<WAVES, PER_WAVE, DEPTH, BARRIER><<<grid, WAVES * 64, lds>>>(buf, steps, wg_stride, 4096, cyc);
+  burst_kernel<WAVES, PER_WAVE, DEPTH, BARRIER, SWZ><<<grid, WAVES * 64, lds>>>(buf, steps, wg_stride, 4096, cyc);
   (void)hipEventRecord(e1);
   (void)hipEventSynchronize(e1);
   float ms;
@@ -93,6 +95,10 @@ int main() {
   run<4, 8, 1>("shared, 4 x 8, wait all, 2 WG/CU", buf, 512, 0, 2);
   run<4, 8, 1>("shared, 4 x 8, wait all, 3 WG/CU", buf, 768, 0, 3);
   run<4, 8, 2>("shared, 4 x 8, one ahead, 2 WG/CU", buf, 512, 0, 2);
+  run<4, 8, 1, true, true>("shared, 4 x 8, wait all, 2 WG/CU, SWIZZLED", buf, 512, 0, 2);
+  run<4, 8, 1, true, true>("shared, 4 x 8, wait all, 1 WG/CU, SWIZZLED", buf, 256, 0, 1);
+  run<4, 12, 1, true, true>("shared, 4 x 12, wait all, 2 WG/CU, SWIZZLED", buf, 512, 0, 2);
+  run<4, 12, 1, true, false>("shared, 4 x 12, wait all, 2 WG/CU", buf, 512, 0, 2);
   // shared window (weights-like): all workgroups read the same 2 MB
   run<4, 8, 1>("shared window: 4 x 8, wait all", buf, 256, 0, 1);
   run<4, 8, 2>("shared window: 4 x 8, one ahead", buf, 256, 0, 1);
