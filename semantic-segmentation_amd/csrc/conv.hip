@@ -65,8 +65,9 @@ struct ConvDev {
   double* stat;
   long long m_begin;     // first pixel of this launch (a problem may be cut into a main and a tail launch)
   long long stat_row0;   // statistic partial row of this launch's first pixel tile
-  int abl;               // timing experiments of the LDS-DMA tile (experiment builds only; results are garbage):
-                         // 7 = no K loop (fixed cost only), 5 = no output stores, 8 = neither tap tables nor K loop
+  int abl;               // timing experiments of the LDS-DMA tile (experiment builds only; results are garbage), a
+                         // bit mask: 1 = every load reads the zero page, 2 = no fragment reads / MFMAs, 4 = no
+                         // per-step address bookkeeping, 8 = no output stores, 16 = no K loop (fixed cost only)
 };
 
 template <typename T>
@@ -195,7 +196,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x4 (&acc)[G::
 
   const int cpad = (p.Cout + 3) & ~3;
   if ((ABL == 5 || ABL == 6) && p.M >= 0) return;
-  if (p.abl == 5) return;
+  if (p.abl & 8) return;
 #pragma unroll
   for (int j = 0; j < MJ; ++j) {
     const long long m = m0 + wc * (MJ * 16) + j * 16 + fr;
@@ -237,6 +238,12 @@ __global__ __launch_bounds__(G::THREADS, (G::THREADS == 256 && G::BCO == 256) ? 
   __shared__ int taps_l[SEGK_MAX_SEG * 9];
   __shared__ int ntaps_l[SEGK_MAX_SEG];
   __shared__ unsigned int mask_l[2];
+  // per listed tap: byte offsets of its weight slice and of its shifted pixel window, and the shift (filled once;
+  // the K loop then reads a table instead of dividing and multiplying per step)
+  __shared__ long long tap_a_l[SEGK_MAX_SEG * 9];
+  __shared__ long long tap_b_l[SEGK_MAX_SEG * 9];
+  __shared__ int tap_dy_l[SEGK_MAX_SEG * 9];
+  __shared__ int tap_dx_l[SEGK_MAX_SEG * 9];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -288,14 +295,25 @@ __global__ __launch_bounds__(G::THREADS, (G::THREADS == 256 && G::BCO == 256) ? 
     if (hi) atomicOr(&mask_l[1], hi);
   }
   __syncthreads();
-  if (tid == 0) {
+  if (tid < SEGK_MAX_SEG * 9) {
+    // thread (segment, tap): a tap that touches the tile takes the list slot given by the number of listed taps
+    // before it
     const unsigned long long all = ((unsigned long long)mask_l[1] << 32) | mask_l[0];
-    for (int sg = 0; sg < p.nseg; ++sg) {
-      int cnt = 0;
-      const int R = p.seg[sg].R;
-      for (int tap = 0; tap < R * R; ++tap)
-        if ((all >> (sg * 9 + tap)) & 1ull) taps_l[sg * 9 + cnt++] = tap;
-      ntaps_l[sg] = cnt;
+    const int sg = tid / 9, tap = tid - sg * 9;
+    if (sg < p.nseg) {
+      const unsigned seg_bits = (unsigned)(all >> (sg * 9)) & 0x1ffu;
+      if (tap == 0) ntaps_l[sg] = __popc(seg_bits);
+      if ((seg_bits >> tap) & 1u) {
+        const SegDev& sd = p.seg[sg];
+        const int slot = sg * 9 + __popc(seg_bits & ((1u << tap) - 1u));
+        const int R = sd.R, dil = sd.dil + (int)blockIdx.y * p.dil_step;
+        const int dy = (tap / R - (R >> 1)) * dil, dx = (tap % R - (R >> 1)) * dil;
+        taps_l[slot] = tap;
+        tap_a_l[slot] = (long long)tap * sd.w_tap_b;
+        tap_b_l[slot] = ((long long)dy * p.W + dx) * sd.in_ld_b;
+        tap_dy_l[slot] = dy;
+        tap_dx_l[slot] = dx;
+      }
     }
   }
   __syncthreads();
@@ -320,21 +338,22 @@ __global__ __launch_bounds__(G::THREADS, (G::THREADS == 256 && G::BCO == 256) ? 
     bool bok[NPB];
     const char* abase = nullptr;
     const char* bbase = nullptr;
+    const char* aseg = nullptr;   // weight rows / pixel rows of this tile in the current segment
+    const char* bseg = nullptr;
     auto setup_seg = [&]() {
       const SegDev& s = p.seg[sg];
 #pragma unroll
       for (int i = 0; i < NPA; ++i) aoff[i] = (unsigned)(wrow[i] - co0) * (unsigned)s.w_ld_b + lc * 16;
 #pragma unroll
       for (int i = 0; i < NPB; ++i) boff[i] = (unsigned)(rm[i] >= m0 ? rm[i] - m0 : 0) * (unsigned)s.in_ld_b + lc * 16;
+      aseg = s.w + bz * s.w_batch_b + (long long)co0 * s.w_ld_b;
+      bseg = s.in + bz * s.in_batch_b + m0 * s.in_ld_b;
     };
     auto setup_tap = [&]() {
-      const SegDev& s = p.seg[sg];
-      const int tap = taps_l[sg * 9 + ti];
-      const int R = s.R;
-      const int dil = s.dil + (int)bz * p.dil_step;
-      const int dy = (tap / R - (R >> 1)) * dil, dx = (tap % R - (R >> 1)) * dil;
-      abase = s.w + bz * s.w_batch_b + (long long)tap * s.w_tap_b + (long long)co0 * s.w_ld_b + (long long)kc * BKB;
-      bbase = s.in + bz * s.in_batch_b + (m0 + (long long)dy * p.W + dx) * s.in_ld_b + (long long)kc * BKB;
+      const int slot = sg * 9 + ti;
+      const int dy = tap_dy_l[slot], dx = tap_dx_l[slot];
+      abase = aseg + tap_a_l[slot] + kc * BKB;
+      bbase = bseg + tap_b_l[slot] + kc * BKB;
 #pragma unroll
       for (int i = 0; i < NPB; ++i)
         bok[i] = rvalid[i] && (unsigned)(ry[i] + dy) < (unsigned)p.H && (unsigned)(rx[i] + dx) < (unsigned)p.W;
@@ -1328,7 +1347,7 @@ __global__ __launch_bounds__(STAGES == 3 ? 512 : 256, (PX == 128 && STAGES == 1)
   __syncthreads();
   int total = 0;
   for (int sg = 0; sg < p.nseg; ++sg) total += ntaps_l[sg] * (p.seg[sg].ck_b / BKB);
-  if (p.abl == 7 || p.abl == 8) total = 0;
+  if (p.abl & 16) total = 0;
 
   f32x4 acc[MI][MJ];
 #pragma unroll
@@ -1365,7 +1384,7 @@ __global__ __launch_bounds__(STAGES == 3 ? 512 : 256, (PX == 128 && STAGES == 1)
         bok[i] = rvalid[i] && (unsigned)(ry[i] + dy) < (unsigned)p.H && (unsigned)(rx[i] + dx) < (unsigned)p.W;
     };
     auto advance = [&]() {
-      if (p.abl == 3) return;           // timing experiment: every step loads the first step's tiles
+      if (p.abl & 4) return;            // timing experiment: every step loads the first step's tiles
       if (++ti >= ntaps_l[sg]) {
         ti = 0;
         if (++kc >= nkc) {
@@ -1388,14 +1407,14 @@ __global__ __launch_bounds__(STAGES == 3 ? 512 : 256, (PX == 128 && STAGES == 1)
     setup_seg();
     setup_tap();
     auto issue = [&](int stage) {
-      const bool fake = p.abl == 1;   // timing experiment: every load reads the zero page
+      const bool fake = p.abl & 1;    // timing experiment: every load reads the zero page
 #pragma unroll
       for (int i = 0; i < 4; ++i) glds16(fake ? zsrc : abase + aoff[i], sa_w + stage * STAGE_B + i * 4096);
 #pragma unroll
       for (int i = 0; i < NB; ++i) glds16(bok[i] && !fake ? bbase + boff[i] : zsrc, sb_w + stage * STAGE_B + i * 4096);
     };
     auto multiply = [&](int stage) {
-      if (p.abl == 2) return;         // timing experiment: loads and barriers only
+      if (p.abl & 2) return;          // timing experiment: loads and barriers only
       const char* a = sa + stage * STAGE_B;
       const char* b = sb + stage * STAGE_B;
 #pragma unroll
