@@ -70,7 +70,7 @@ def parse():
     ap.add_argument("--overlap-wgrad", choices=["auto", "on", "off"], default="auto",
                     help="segk.config.set_overlap_wgrad: weight gradients on a second HIP stream (auto: with --graph)")
     ap.add_argument("--feeder-conv", choices=["auto", "hip", "torch"], default=None,
-                    help="segk.config.set_feeder_conv: which kernels run the feeder's layer-3/4 3x3 convolutions "
+                    help="segk.config.set_feeder_conv: which kernels run the feeder's stride-1 3x3 convolutions of layers 2-4 "
                          "(default: the package default)")
     ap.add_argument("--sync-bn", choices=["auto", "on", "off"], default="on",
                     help="SynchronizedBatchNorm2d (HIP) in every layer, the reference's --sync-bn (train.py:321-322); "
@@ -470,8 +470,8 @@ def main():
                               "share_of_step": fd["ms"] / (1000.0 * elapsed)},
                 "wgrad": {"achieved": a2, "frac": a2 / peak, "launches": fw["launches"], "avg_launch_ms": fw["avg_ms"],
                           "share_of_step": fw["ms"] / (1000.0 * elapsed)},
-                "kernel": "the same kernels on the 25 stride-1 3x3 bottleneck convolutions of ResNet layers 3 and 4 "
-                          "(M = 17 424 pixels, 256 or 512 channels): small launches, a third of their time is fixed cost"}
+                "kernel": "the same kernels on the 28 stride-1 3x3 bottleneck convolutions of ResNet layers 2 to 4 "
+                          "(65 x 65 and 33 x 33 maps, 128 to 512 channels): small launches, a third of their time is fixed cost"}
         return out
 
     main_res = measure(args.dtype, args.steps, args.warmup, not args.no_kernel_timing)

@@ -41,8 +41,8 @@ def legacy_clamp_eps():
 
 
 def set_feeder_conv(mode):
-    """Which kernels run the feeder's stride-1 3x3 bottleneck convolutions with 256 or more channels
-    (/root/reference/newmodeling/backbone/resnet101_2.py:19-21; ResNet layers 3 and 4) together with the batch norm
+    """Which kernels run the feeder's stride-1 3x3 bottleneck convolutions with 128 or more channels
+    (/root/reference/newmodeling/backbone/resnet101_2.py:19-21; ResNet layers 2 to 4) together with the batch norm
     and ReLU behind them, when that batch norm is a SynchronizedBatchNorm2d:
       "auto"  (default) the HIP implicit-GEMM kernels when the activation already is pixel-major memory
               (a channels_last feeder, e.g. under bf16 autocast), PyTorch-ROCm / MIOpen otherwise;

@@ -356,7 +356,7 @@ def test_e2e_first_step_gradients_all_parameters(impl):
 
 
 def test_e2e_first_step_gradients_hip_feeder_convs(impl_sync):
-    """The feeder's 25 stride-1 3x3 bottleneck convolutions of layers 3 and 4 on the implicit-GEMM kernels (statistics
+    """The feeder's 28 stride-1 3x3 bottleneck convolutions of layers 2 to 4 on the implicit-GEMM kernels (statistics
     from the convolution epilogue), HIP batch norm in every feeder layer.  Every ReLU of the network reports its
     activation pattern and the oracle (its feeder convolutions on MIOpen) is evaluated on that pattern: loss and ALL
     parameter gradients, feeder included, at the head's gates.  Only the stem (conv1 / bn1, in front of the max
