@@ -127,7 +127,15 @@ __global__ void wgrad_finish_kernel(const float* __restrict__ slabs, int splits,
     float acc = 0.f;
     if (ci < Cin && co < Cout) {
       const float* p = slabs + ((size_t)tap * Cin + ci) * Cout + co;
-      for (int s = 0; s < splits; ++s) acc += p[s * slab];
+      int s = 0;
+      for (; s + 8 <= splits; s += 8) {   // eight loads in flight, added in slab order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(s + u) * slab];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+      }
+      for (; s < splits; ++s) acc += p[(size_t)s * slab];
     }
     tile[ty + i * 8][tx] = acc;
   }

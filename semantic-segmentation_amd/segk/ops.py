@@ -304,7 +304,7 @@ def default_splits(M, Cin, Cout, R, dtype):
     return wgrad_plan(M, Cin, Cout, R, dtype)[1]
 
 
-def conv_wgrad(x, dout, N, H, W, R, dil, Cout_true, Cin_true, splits=None, like=None):
+def conv_wgrad(x, dout, N, H, W, R, dil, Cout_true, Cin_true, splits=None, like=None, tile=0):
     """Weight gradient [Cout_true, Cin_true, R, R] from the forward input view x [M, Cin_pad] and the output gradient
     view dout [M, Cout_pad] (padded channels must hold zeros): contiguous fp32, or with the dtype and strides of
     the weight `like` (what autograd expects for a bf16 / channels_last parameter)."""
@@ -314,8 +314,7 @@ def conv_wgrad(x, dout, N, H, W, R, dil, Cout_true, Cin_true, splits=None, like=
     do_ld, Cout = _pm(dout)
     if x.shape[0] != M or dout.shape[0] != M or x.dtype != dout.dtype:
         raise ValueError("wgrad operands disagree: %s %s M=%d" % (tuple(x.shape), tuple(dout.shape), M))
-    tile = 0
-    if splits is None:
+    if splits is None:   # (an explicit `splits` leaves the tile to the library unless `tile` names it: 128 or 256)
         tile, splits = wgrad_plan(M, Cin, Cout, R, x.dtype)
     slabs = torch.empty((splits, R * R, Cin, Cout), dtype=torch.float32, device=x.device)
     a = WgradArgs()
