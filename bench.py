@@ -283,10 +283,6 @@ def main():
     dev = torch.device("cuda", local)
     if args.feeder_conv is not None:
         config.set_feeder_conv(args.feeder_conv)
-    elif world > 1 or args.graph == "off" or args.optimizer != "hip":
-        # issued launch by launch, the fused convolution + batch-norm units of the feeder cost the host more than
-        # they save the GPU (measured: 36.2 against 34.1 ms/step); replayed from a graph they win (33.4 against 33.8)
-        config.set_feeder_conv("torch")
     search = not args.no_miopen_benchmark
     if rank == 0:
         heartbeat()
