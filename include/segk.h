@@ -252,27 +252,32 @@ int segk_bn_coeffs_eval(const float* running_mean, const float* running_var, con
  * with leading dimension C; the kept values are multiplied by mask_scale = 1/(1-p)).
  * (batchnorm.py:73, modeling/aspp.py:21,147, modeling/decoder.py:145-151)
  * res (NULL, or pixel-major [M][res_ld] of y's dtype) is added before the ReLU: the shortcut of a bottleneck block
- * (modeling/backbone/resnet101.py Bottleneck.forward: bn3 -> += residual -> relu) in the same pass. */
+ * (modeling/backbone/resnet101.py Bottleneck.forward: bn3 -> += residual -> relu) in the same pass.
+ * relu_bits (NULL, or [M][relu_bits_ld] bytes, relu_bits_ld >= C / 8; pixel-major layout with C, the leading
+ * dimensions and the operand addresses multiples of 8 elements / 16 bytes) receives the ReLU pattern of the stored
+ * output: bit j of byte [m][c / 8] is set when y[m][8 * (c / 8) + j] > 0.  The backward passes read it in place of
+ * the stored output (1/16 of its bytes). */
 int segk_bn_apply(const void* x, int x_dtype, int x_ld, void* y, int y_dtype, int y_ld, int layout, int N, int C,
                   int HW, const float* scale, const float* shift, int relu, const uint8_t* mask,
-                  float mask_scale, const void* res, int res_ld, segk_stream_t stream);
+                  float mask_scale, const void* res, int res_ld, uint8_t* relu_bits, int relu_bits_ld,
+                  segk_stream_t stream);
 /* Backward, pass 1: with g = dz * mask * [relu active], per-channel partial sums of g and g*xhat.
  * partials: [segk_bn_stat_rows(...)][2][C].  act (NULL, or pixel-major [M][act_ld] of dz's dtype) is the layer's
  * stored output when a residual was added before the ReLU; the ReLU pattern is then act > 0 instead of
- * x*scale + shift > 0. */
+ * x*scale + shift > 0.  act_bits != 0: act points to the bit pattern segk_bn_apply wrote ([M][act_ld] bytes). */
 int segk_bn_bwd_stats(const void* dz, int dz_dtype, int dz_ld, const void* x, int x_dtype, int x_ld, int layout,
                       int N, int C, int HW, const float* mean, const float* inv_std, const float* scale,
                       const float* shift, int relu, const uint8_t* mask, float mask_scale, const void* act,
-                      int act_ld, double* partials, segk_stream_t stream);
-/* Backward, pass 2 (act as in pass 1; dres, NULL or [M][dres_ld] of dz's dtype, receives g = the gradient of the
- * residual input): dx = scale * (g - sum_g/count - xhat * sum_gxhat/count) with the GLOBAL sums
+                      int act_ld, int act_bits, double* partials, segk_stream_t stream);
+/* Backward, pass 2 (act / act_bits as in pass 1; dres, NULL or [M][dres_ld] of dz's dtype, receives g = the gradient
+ * of the residual input): dx = scale * (g - sum_g/count - xhat * sum_gxhat/count) with the GLOBAL sums
  * gsums = [sum g (C), sum g*xhat (C), count] (autograd of batchnorm.py:66-73 through the reduction);
  * eval != 0: dx = scale * g.  */
 int segk_bn_bwd_apply(const void* dz, int dz_dtype, int dz_ld, const void* x, int x_dtype, int x_ld, void* dx,
                       int dx_dtype, int dx_ld, int layout, int N, int C, int HW, const float* mean,
                       const float* inv_std, const float* scale, const float* shift, int relu,
                       const uint8_t* mask, float mask_scale, const double* gsums, int eval, const void* act,
-                      int act_ld, void* dres, int dres_ld, segk_stream_t stream);
+                      int act_ld, int act_bits, void* dres, int dres_ld, segk_stream_t stream);
 
 /* ---- pooling / resampling ------------------------------------------------------------------- */
 /* nn.AdaptiveAvgPool2d((1,1)) on a pixel-major tensor (modeling/aspp.py:121): out[n][c] fp32 =

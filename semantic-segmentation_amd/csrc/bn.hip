@@ -186,7 +186,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_pm_kernel(const TX* __res
 template <int VEC>
 __device__ __forceinline__ void grad_through_act(float (&gz)[VEC], const float (&xv)[VEC], const float* sc,
                                                  const float* sh, int relu, const uint8_t* mask_p, float mask_scale,
-                                                 const float* act = nullptr) {
+                                                 const float* act = nullptr, int bits = -1) {
   if (mask_p) {
     float mk[VEC];
     load_mask<VEC>(mask_p, mk);
@@ -194,15 +194,23 @@ __device__ __forceinline__ void grad_through_act(float (&gz)[VEC], const float (
     for (int j = 0; j < VEC; ++j) gz[j] *= mk[j] * mask_scale;
   }
   if (relu) {
+    if (bits >= 0) {   // the stored ReLU pattern, one bit per channel of this thread's group
 #pragma unroll
-    for (int j = 0; j < VEC; ++j)
-      if (!((act ? act[j] : fmaf(xv[j], sc[j], sh[j])) > 0.f)) gz[j] = 0.f;
+      for (int j = 0; j < VEC; ++j)
+        if (!((bits >> j) & 1)) gz[j] = 0.f;
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+        if (!((act ? act[j] : fmaf(xv[j], sc[j], sh[j])) > 0.f)) gz[j] = 0.f;
+    }
   }
 }
 
-// RES: the layer added a residual before its ReLU; `act` (its stored output) then gives the ReLU pattern.  A template
-// flag, not a run-time test: a branch around a load keeps the compiler from issuing the row's loads together.
-template <typename TG, typename TX, int VEC, bool RES>
+// RES: the layer added a residual before its ReLU; the ReLU pattern then comes from the layer's stored output `act`
+// (RES = 1) or from the bit pattern the forward apply stored, one byte per pixel and group of eight channels
+// (RES = 2, VEC = 8: `act` then points to those bytes, act_ld bytes per pixel).  A template flag, not a run-time
+// test: a branch around a load keeps the compiler from issuing the row's loads together.
+template <typename TG, typename TX, int VEC, int RES>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_pm_kernel(
     const TG* __restrict__ dz, int dz_ld, const TX* __restrict__ x, int x_ld, long long M, int C,
     const float* __restrict__ mean, const float* __restrict__ inv_std, const float* __restrict__ scale,
@@ -231,16 +239,18 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_pm_kernel(
     long long m = t.m0 + t.pr;
     for (; m + step < t.m1; m += 2 * step) {
       float gz[2][VEC], xv[2][VEC], av[2][VEC];
+      int bits[2] = {-1, -1};
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         load_vec<TG, VEC>(dz + (m + k * step) * dz_ld + c0, gz[k]);
         load_vec<TX, VEC>(x + (m + k * step) * x_ld + c0, xv[k]);
-        if (RES) load_vec<TG, VEC>(act + (m + k * step) * act_ld + c0, av[k]);
+        if (RES == 1) load_vec<TG, VEC>(act + (m + k * step) * act_ld + c0, av[k]);
+        if (RES == 2) bits[k] = reinterpret_cast<const uint8_t*>(act)[(m + k * step) * act_ld + (c0 >> 3)];
       }
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         grad_through_act<VEC>(gz[k], xv[k], sc, sh, relu, mask ? mask + (m + k * step) * C + c0 : nullptr, mask_scale,
-                              RES ? av[k] : nullptr);
+                              RES == 1 ? av[k] : nullptr, bits[k]);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           a[j] += gz[k][j];
@@ -250,10 +260,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_pm_kernel(
     }
     for (; m < t.m1; m += step) {
       float gz[VEC], xv[VEC], av[VEC];
+      int bits = -1;
       load_vec<TG, VEC>(dz + m * dz_ld + c0, gz);
       load_vec<TX, VEC>(x + m * x_ld + c0, xv);
-      if (RES) load_vec<TG, VEC>(act + m * act_ld + c0, av);
-      grad_through_act<VEC>(gz, xv, sc, sh, relu, mask ? mask + m * C + c0 : nullptr, mask_scale, RES ? av : nullptr);
+      if (RES == 1) load_vec<TG, VEC>(act + m * act_ld + c0, av);
+      if (RES == 2) bits = reinterpret_cast<const uint8_t*>(act)[m * act_ld + (c0 >> 3)];
+      grad_through_act<VEC>(gz, xv, sc, sh, relu, mask ? mask + m * C + c0 : nullptr, mask_scale,
+                            RES == 1 ? av : nullptr, bits);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         a[j] += gz[j];
@@ -270,7 +283,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_pm_kernel(const TX* __res
                                                                   const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, int relu,
                                                                   const uint8_t* __restrict__ mask, float mask_scale,
-                                                                  const TY* __restrict__ res, int res_ld) {
+                                                                  const TY* __restrict__ res, int res_ld,
+                                                                  uint8_t* __restrict__ relu_bits, int bits_ld) {
   const PmThread t = pm_thread<VEC>(C, M);
   if (!t.active) return;
   const int c0 = t.c_base + t.cgi * VEC;
@@ -282,13 +296,22 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_pm_kernel(const TX* __res
     float v[VEC], o[VEC], rv[VEC];
     load_vec<TX, VEC>(x + m * x_ld + c0, v);
     if (RES) load_vec<TY, VEC>(res + m * res_ld + c0, rv);
+    unsigned pattern = 0u;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float r = fmaf(v[j], sc[j], sh[j]);
       if (RES) r += rv[j];   // residual added before the ReLU (bottleneck shortcut)
+      if (VEC == 8) {
+        // the pattern is taken from the value as it is stored (rounded to TY): what the backward would otherwise
+        // read back from y
+        float q = r;
+        if (sizeof(TY) == 2) q = bf16_to_f32(f32_to_bf16(r));
+        pattern |= (q > 0.f ? 1u : 0u) << j;
+      }
       if (relu) r = r > 0.f ? r : 0.f;
       o[j] = r;
     }
+    if (VEC == 8 && relu_bits) relu_bits[m * bits_ld + (c0 >> 3)] = (uint8_t)pattern;
     if (mask) {
       float mk[VEC];
       load_mask<VEC>(mask + m * C + c0, mk);
@@ -299,7 +322,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_pm_kernel(const TX* __res
   }
 }
 
-template <typename TG, typename TX, int VEC, bool RES>
+template <typename TG, typename TX, int VEC, int RES>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_pm_kernel(
     const TG* __restrict__ dz, int dz_ld, const TX* __restrict__ x, int x_ld, TG* __restrict__ dx, int dx_ld,
     long long M, int C, const float* __restrict__ mean, const float* __restrict__ inv_std,
@@ -335,10 +358,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_pm_kernel(
 #pragma unroll 2
   for (long long m = t.m0 + t.pr; m < t.m1; m += t.rpb) {
     float gz[VEC], xv[VEC], o[VEC], av[VEC];
+    int bits = -1;
     load_vec<TG, VEC>(dz + m * dz_ld + c0, gz);
     load_vec<TX, VEC>(x + m * x_ld + c0, xv);
-    if (RES) load_vec<TG, VEC>(act + m * act_ld + c0, av);
-    grad_through_act<VEC>(gz, xv, sc, sh, relu, mask ? mask + m * C + c0 : nullptr, mask_scale, RES ? av : nullptr);
+    if (RES == 1) load_vec<TG, VEC>(act + m * act_ld + c0, av);
+    if (RES == 2) bits = reinterpret_cast<const uint8_t*>(act)[m * act_ld + (c0 >> 3)];
+    grad_through_act<VEC>(gz, xv, sc, sh, relu, mask ? mask + m * C + c0 : nullptr, mask_scale,
+                          RES == 1 ? av : nullptr, bits);
     if (RES) store_vec<TG, VEC>(dres + m * dres_ld + c0, gz);   // gradient of the residual input
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
@@ -738,7 +764,8 @@ extern "C" int segk_bn_coeffs_eval(const float* running_mean, const float* runni
 
 extern "C" int segk_bn_apply(const void* x, int x_dtype, int x_ld, void* y, int y_dtype, int y_ld, int layout, int N,
                              int C, int HW, const float* scale, const float* shift, int relu, const uint8_t* mask,
-                             float mask_scale, const void* res, int res_ld, segk_stream_t stream) {
+                             float mask_scale, const void* res, int res_ld, uint8_t* relu_bits, int relu_bits_ld,
+                             segk_stream_t stream) {
   SEGK_REQUIRE(x && y && scale && shift && valid_dtype(x_dtype) && valid_dtype(y_dtype),
                "bn_apply: null pointer or bad dtype");
   BN_COMMON_CHECK("bn_apply");
@@ -748,15 +775,21 @@ extern "C" int segk_bn_apply(const void* x, int x_dtype, int x_ld, void* y, int 
     const long long M = (long long)N * HW;
     const int vec = res ? pm_vec(C, {x_ld, y_ld, res_ld}, {{x, x_dtype}, {y, y_dtype}, {res, y_dtype}}, mask)
                         : pm_vec(C, {x_ld, y_ld}, {{x, x_dtype}, {y, y_dtype}}, mask);
+    SEGK_REQUIRE(!relu_bits || relu_bits_ld * 8 >= C, "bn_apply: relu_bits_ld %d < C / 8 (C = %d)", relu_bits_ld, C);
+    SEGK_UNSUPPORTED(!relu_bits || vec == 8,
+                     "bn_apply: the ReLU bit pattern needs C and the leading dimensions to be multiples of 8 and "
+                     "16-byte aligned operands");
     const dim3 grid = pm_apply_grid(M, C, vec);
 #define LAUNCH_APPLY(TX, TY)                                                                                       \
   SEGK_DISPATCH_VEC(vec, V, {                                                                                      \
     if (res)                                                                                                       \
       bn_apply_pm_kernel<TX, TY, V, true><<<grid, BN_THREADS, 0, st>>>((const TX*)x, x_ld, (TY*)y, y_ld, M, C, scale, \
-                                                                       shift, relu, mask, mask_scale, (const TY*)res, res_ld); \
+                                                                       shift, relu, mask, mask_scale, (const TY*)res, res_ld, \
+                                                                       relu_bits, relu_bits_ld);                       \
     else                                                                                                           \
       bn_apply_pm_kernel<TX, TY, V, false><<<grid, BN_THREADS, 0, st>>>((const TX*)x, x_ld, (TY*)y, y_ld, M, C, scale, \
-                                                                        shift, relu, mask, mask_scale, nullptr, 0); \
+                                                                        shift, relu, mask, mask_scale, nullptr, 0,  \
+                                                                        relu_bits, relu_bits_ld);                      \
   })
     if (x_dtype == SEGK_BF16 && y_dtype == SEGK_BF16) { LAUNCH_APPLY(bf16_t, bf16_t); }
     else if (x_dtype == SEGK_BF16) { LAUNCH_APPLY(bf16_t, float); }
@@ -764,7 +797,7 @@ extern "C" int segk_bn_apply(const void* x, int x_dtype, int x_ld, void* y, int 
     else { LAUNCH_APPLY(float, float); }
 #undef LAUNCH_APPLY
   } else {
-    SEGK_REQUIRE(!res, "bn_apply: the residual input needs the pixel-major layout");
+    SEGK_REQUIRE(!res && !relu_bits, "bn_apply: the residual input and the ReLU bit pattern need the pixel-major layout");
     const long long planes = (long long)N * C;
     dim3 grid((unsigned)planes, nchw_apply_slices(planes, HW));
 #define LAUNCH_APPLY(TX, TY) \
@@ -782,29 +815,36 @@ extern "C" int segk_bn_apply(const void* x, int x_dtype, int x_ld, void* y, int 
 extern "C" int segk_bn_bwd_stats(const void* dz, int dz_dtype, int dz_ld, const void* x, int x_dtype, int x_ld,
                                  int layout, int N, int C, int HW, const float* mean, const float* inv_std,
                                  const float* scale, const float* shift, int relu, const uint8_t* mask,
-                                 float mask_scale, const void* act, int act_ld, double* partials,
+                                 float mask_scale, const void* act, int act_ld, int act_bits, double* partials,
                                  segk_stream_t stream) {
   SEGK_REQUIRE(dz && x && mean && inv_std && scale && shift && partials && valid_dtype(dz_dtype) && valid_dtype(x_dtype),
                "bn_bwd_stats: null pointer or bad dtype");
   BN_COMMON_CHECK("bn_bwd_stats");
   hipStream_t st = (hipStream_t)stream;
   if (layout == SEGK_PM) {
-    SEGK_REQUIRE(x_ld >= C && dz_ld >= C && (!act || act_ld >= C), "bn_bwd_stats: ld (%d,%d,%d) < C %d", dz_ld, x_ld, act_ld, C);
+    SEGK_REQUIRE(x_ld >= C && dz_ld >= C && (!act || (act_bits ? act_ld * 8 >= C : act_ld >= C)),
+                 "bn_bwd_stats: ld (%d,%d,%d) < C %d", dz_ld, x_ld, act_ld, C);
+    SEGK_REQUIRE(!act_bits || act, "bn_bwd_stats: act_bits without act");
     const long long M = (long long)N * HW;
     const int rows = pm_rows(M, C);
-    const int vec = act ? pm_vec(C, {x_ld, dz_ld, act_ld}, {{x, x_dtype}, {dz, dz_dtype}, {act, dz_dtype}}, mask)
-                        : pm_vec(C, {x_ld, dz_ld}, {{x, x_dtype}, {dz, dz_dtype}}, mask);
+    const int vec = (act && !act_bits) ? pm_vec(C, {x_ld, dz_ld, act_ld}, {{x, x_dtype}, {dz, dz_dtype}, {act, dz_dtype}}, mask)
+                                       : pm_vec(C, {x_ld, dz_ld}, {{x, x_dtype}, {dz, dz_dtype}}, mask);
+    SEGK_UNSUPPORTED(!act_bits || vec == 8, "bn_bwd_stats: the ReLU bit pattern needs 8-channel vector access");
     const int slab = pm_stat_slab(C);
     const size_t lds = (size_t)4 * slab * sizeof(float);
 #define LAUNCH_BS(TG, TX)                                                                                           \
   SEGK_DISPATCH_VEC(vec, V, {                                                                                       \
     const dim3 grid_(rows, ceil_div(C, slab));                                                                      \
-    if (act)                                                                                                        \
-      bn_bwd_stats_pm_kernel<TG, TX, V, true><<<grid_, BN_THREADS, lds, st>>>(                                      \
+    if (act && act_bits)                                                                                            \
+      bn_bwd_stats_pm_kernel<TG, TX, V, 2><<<grid_, BN_THREADS, lds, st>>>(                                         \
+          (const TG*)dz, dz_ld, (const TX*)x, x_ld, M, C, mean, inv_std, scale, shift, relu, mask, mask_scale,      \
+          (const TG*)act, act_ld, slab, partials);                                                                  \
+    else if (act)                                                                                                   \
+      bn_bwd_stats_pm_kernel<TG, TX, V, 1><<<grid_, BN_THREADS, lds, st>>>(                                         \
           (const TG*)dz, dz_ld, (const TX*)x, x_ld, M, C, mean, inv_std, scale, shift, relu, mask, mask_scale,      \
           (const TG*)act, act_ld, slab, partials);                                                                  \
     else                                                                                                            \
-      bn_bwd_stats_pm_kernel<TG, TX, V, false><<<grid_, BN_THREADS, lds, st>>>(                                     \
+      bn_bwd_stats_pm_kernel<TG, TX, V, 0><<<grid_, BN_THREADS, lds, st>>>(                                         \
           (const TG*)dz, dz_ld, (const TX*)x, x_ld, M, C, mean, inv_std, scale, shift, relu, mask, mask_scale,      \
           nullptr, 0, slab, partials);                                                                              \
   })
@@ -833,7 +873,8 @@ extern "C" int segk_bn_bwd_apply(const void* dz, int dz_dtype, int dz_ld, const 
                                  int dx_dtype, int dx_ld, int layout, int N, int C, int HW, const float* mean,
                                  const float* inv_std, const float* scale, const float* shift, int relu,
                                  const uint8_t* mask, float mask_scale, const double* gsums, int eval,
-                                 const void* act, int act_ld, void* dres, int dres_ld, segk_stream_t stream) {
+                                 const void* act, int act_ld, int act_bits, void* dres, int dres_ld,
+                                 segk_stream_t stream) {
   SEGK_REQUIRE(dz && x && dx && mean && inv_std && scale && shift && valid_dtype(dz_dtype) && valid_dtype(x_dtype),
                "bn_bwd_apply: null pointer or bad dtype");
   SEGK_REQUIRE(dx_dtype == dz_dtype, "bn_bwd_apply: dx dtype must equal dz dtype");
@@ -844,20 +885,27 @@ extern "C" int segk_bn_bwd_apply(const void* dz, int dz_dtype, int dz_ld, const 
     SEGK_REQUIRE(x_ld >= C && dz_ld >= C && dx_ld >= C, "bn_bwd_apply: ld (%d,%d,%d) < C %d", dz_ld, x_ld, dx_ld, C);
     const long long M = (long long)N * HW;
     SEGK_REQUIRE((act != nullptr) == (dres != nullptr), "bn_bwd_apply: a stored activation and a residual gradient come together");
-    SEGK_REQUIRE((!act || act_ld >= C) && (!dres || dres_ld >= C), "bn_bwd_apply: ld (%d,%d) < C %d", act_ld, dres_ld, C);
+    SEGK_REQUIRE((!act || (act_bits ? act_ld * 8 >= C : act_ld >= C)) && (!dres || dres_ld >= C),
+                 "bn_bwd_apply: ld (%d,%d) < C %d", act_ld, dres_ld, C);
+    SEGK_REQUIRE(!act_bits || act, "bn_bwd_apply: act_bits without act");
     int vec = pm_vec(C, {x_ld, dz_ld, dx_ld}, {{x, x_dtype}, {dz, dz_dtype}, {dx, dx_dtype}}, mask);
-    if (act) vec = std::min(vec, pm_vec(C, {act_ld}, {{act, dz_dtype}}, nullptr));
+    if (act && !act_bits) vec = std::min(vec, pm_vec(C, {act_ld}, {{act, dz_dtype}}, nullptr));
     if (dres) vec = std::min(vec, pm_vec(C, {dres_ld}, {{dres, dz_dtype}}, nullptr));
+    SEGK_UNSUPPORTED(!act_bits || vec == 8, "bn_bwd_apply: the ReLU bit pattern needs 8-channel vector access");
     const dim3 grid = pm_apply_grid(M, C, vec);
     const size_t lds = (size_t)6 * (C < BN_THREADS * vec ? C : BN_THREADS * vec) * sizeof(float);
 #define LAUNCH_BA(TG, TX)                                                                                            \
   SEGK_DISPATCH_VEC(vec, V, {                                                                                        \
-    if (act)                                                                                                         \
-      bn_bwd_apply_pm_kernel<TG, TX, V, true><<<grid, BN_THREADS, lds, st>>>(                                        \
+    if (act && act_bits)                                                                                             \
+      bn_bwd_apply_pm_kernel<TG, TX, V, 2><<<grid, BN_THREADS, lds, st>>>(                                           \
+          (const TG*)dz, dz_ld, (const TX*)x, x_ld, (TG*)dx, dx_ld, M, C, mean, inv_std, scale, shift, relu, mask,   \
+          mask_scale, gsums, eval, (const TG*)act, act_ld, (TG*)dres, dres_ld);                                      \
+    else if (act)                                                                                                    \
+      bn_bwd_apply_pm_kernel<TG, TX, V, 1><<<grid, BN_THREADS, lds, st>>>(                                           \
           (const TG*)dz, dz_ld, (const TX*)x, x_ld, (TG*)dx, dx_ld, M, C, mean, inv_std, scale, shift, relu, mask,   \
           mask_scale, gsums, eval, (const TG*)act, act_ld, (TG*)dres, dres_ld);                                      \
     else                                                                                                             \
-      bn_bwd_apply_pm_kernel<TG, TX, V, false><<<grid, BN_THREADS, lds, st>>>(                                       \
+      bn_bwd_apply_pm_kernel<TG, TX, V, 0><<<grid, BN_THREADS, lds, st>>>(                                           \
           (const TG*)dz, dz_ld, (const TX*)x, x_ld, (TG*)dx, dx_ld, M, C, mean, inv_std, scale, shift, relu, mask,   \
           mask_scale, gsums, eval, nullptr, 0, nullptr, 0);                                                          \
   })

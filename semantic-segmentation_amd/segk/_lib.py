@@ -87,13 +87,13 @@ SIGNATURES = {
     "segk_bn_coeffs_eval": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_int, c_void_p],
     "segk_bn_apply": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
-                      c_void_p, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p],
+                      c_void_p, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p, c_int, c_void_p],
     "segk_bn_bwd_stats": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
-                          c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p,
+                          c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p,
                           c_void_p],
     "segk_bn_bwd_apply": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
                           c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float,
-                          c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
+                          c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p],
     "segk_pool_sum": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p],
     "segk_upsample_fwd": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
                           c_int, c_void_p],

@@ -598,6 +598,11 @@ def upsample_cross_entropy(x, target, weight=None, ignore_index=255, size_averag
 
 
 # ----------------------------------------------------------------- SyncBN ----
+def _pm_aligned8(v):
+    """Whether a pixel-major view allows the kernels' 8-channel vector access."""
+    return v.shape[1] % 8 == 0 and v.stride(0) % 8 == 0 and v.data_ptr() % 16 == 0
+
+
 class SyncBNFunction(torch.autograd.Function):
     """Stand-alone batch norm on NCHW (or channels_last) tensors: the feeder's layers.  Optionally with the ReLU
     that follows it, and with the residual that a bottleneck block adds in between, in the same passes."""
@@ -623,16 +628,22 @@ class SyncBNFunction(torch.autograd.Function):
             coef = _train_coeffs(partials, cnt, spec, gamma, beta)
         else:
             coef = ops.bn_coeffs_eval(spec.running_mean, spec.running_var, gamma, beta, spec.eps)
+        bits = None
         if layout == PM:
             y = torch.empty_like(x, memory_format=torch.channels_last)
-            ops.bn_apply(xv, pm_view_of(y), coef, PM, relu, res=rv)
+            yv = pm_view_of(y)
+            if rv is not None and relu:
+                # with a residual the backward cannot recompute the ReLU pattern from x; it gets one bit per element
+                # (1/16 of re-reading the bf16 output) when the vector kernels apply, else the output itself
+                bits = ops.relu_bits_like(yv) if (_pm_aligned8(xv) and _pm_aligned8(rv)) else None
+            ops.bn_apply(xv, yv, coef, PM, relu, res=rv, relu_bits=bits)
         else:
             y = torch.empty_like(xv)
             ops.bn_apply(xv, y, coef, NCHW, relu)
         if CAPTURE is not None and relu:
             CAPTURE.append((y, None))   # already NCHW-shaped
         # without a residual the ReLU pattern is recomputed from x*scale + shift; with one it is read from y
-        act = pm_view_of(y) if (rv is not None and relu) else None
+        act = (bits if bits is not None else pm_view_of(y)) if (rv is not None and relu) else None
         ctx.saved = (xv, coef, layout, spec.training, spec.sync, x.dtype, shape, relu, act, rv is not None)
         ctx.affine = gamma is not None
         return y if y.dtype == x.dtype else y.to(x.dtype)

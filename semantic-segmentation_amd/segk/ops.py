@@ -594,8 +594,30 @@ def _pm_operand(t, like, name, layout):
     return _ptr(t), ld
 
 
-def bn_apply(x, y, coef, layout, relu, mask=None, mask_scale=1.0, res=None):
-    """y = relu?(x*scale + shift [+ res]) * mask; res (pixel-major, y's dtype) is the shortcut of a residual block."""
+def relu_bits_like(y):
+    """An empty [M, C/8] uint8 tensor for the ReLU bit pattern of the pixel-major view y, or None when the kernels'
+    8-channel vector access does not apply to it."""
+    ld, C = _pm(y)
+    if C % 8 or ld % 8 or y.data_ptr() % 16:
+        return None
+    return torch.empty((y.shape[0], C // 8), dtype=torch.uint8, device=y.device)
+
+
+def _act_operand(act, x, layout):
+    """(pointer, ld, is_bits) of the stored ReLU information of a residual layer: its output (x's shape) or the
+    [M, C/8] uint8 bit pattern bn_apply wrote."""
+    if act is not None and act.dtype == torch.uint8:
+        if layout != PM or act.dim() != 2 or act.shape[0] != x.shape[0] or act.shape[1] * 8 < x.shape[1] or not act.is_contiguous():
+            raise ValueError("the ReLU bit pattern is a contiguous uint8 [M, C/8] tensor beside pixel-major operands")
+        _dev(act)
+        return _ptr(act), act.shape[1], 1
+    ap, a_ld = _pm_operand(act, x, "stored activation", layout)
+    return ap, a_ld, 0
+
+
+def bn_apply(x, y, coef, layout, relu, mask=None, mask_scale=1.0, res=None, relu_bits=None):
+    """y = relu?(x*scale + shift [+ res]) * mask; res (pixel-major, y's dtype) is the shortcut of a residual block.
+    relu_bits (from relu_bits_like(y)) receives one bit per element: y > 0."""
     _dev(x, y, coef)
     N, C, HW, x_ld = _bn_geom(x, layout)
     y_ld = _pm(y)[0] if layout == PM else 0
@@ -608,8 +630,9 @@ def bn_apply(x, y, coef, layout, relu, mask=None, mask_scale=1.0, res=None):
     r = _row_ptrs(coef)
     t0 = _hbm_start()
     call("segk_bn_apply", _ptr(x), _dt(x), x_ld, _ptr(y), _dt(y), y_ld, layout, N, C, HW, r[2], r[3],
-         1 if relu else 0, _ptr(mask), ctypes.c_float(mask_scale), rp, r_ld, _stream())
-    _hbm_stop("bn_apply", _nbytes(x, y, res, mask), t0)
+         1 if relu else 0, _ptr(mask), ctypes.c_float(mask_scale), rp, r_ld, _ptr(relu_bits),
+         relu_bits.shape[1] if relu_bits is not None else 0, _stream())
+    _hbm_stop("bn_apply", _nbytes(x, y, res, mask, relu_bits), t0)
     return y
 
 
@@ -622,15 +645,15 @@ def bn_bwd_stat_partials(dz, x, coef, layout, relu, mask=None, mask_scale=1.0, a
     if layout == NCHW and not dz.is_contiguous():
         raise ValueError("NCHW gradient must be contiguous")
     _mask_check(mask, x)
-    if act is not None and act.dtype != dz.dtype:
+    if act is not None and act.dtype not in (dz.dtype, torch.uint8):
         raise ValueError("the stored activation has the gradient's dtype")
-    ap, a_ld = _pm_operand(act, x, "stored activation", layout)
+    ap, a_ld, a_bits = _act_operand(act, x, layout)
     rows = call("segk_bn_stat_rows", layout, N, C, HW)
     partials = torch.empty((rows, 2, C), dtype=torch.float64, device=x.device)
     r = _row_ptrs(coef)
     t0 = _hbm_start()
     call("segk_bn_bwd_stats", _ptr(dz), _dt(dz), dz_ld, _ptr(x), _dt(x), x_ld, layout, N, C, HW, r[0], r[1], r[2], r[3],
-         1 if relu else 0, _ptr(mask), ctypes.c_float(mask_scale), ap, a_ld, _ptr(partials), _stream())
+         1 if relu else 0, _ptr(mask), ctypes.c_float(mask_scale), ap, a_ld, a_bits, _ptr(partials), _stream())
     _hbm_stop("bn_bwd_stats", _nbytes(dz, x, act, mask), t0)
     return partials, float(N * HW)
 
@@ -650,15 +673,15 @@ def bn_bwd_apply(dz, x, dx, coef, gsums, layout, relu, mask=None, mask_scale=1.0
     dx_ld = _pm(dx)[0] if layout == PM else 0
     _mask_check(mask, x)
     for t, nm in ((act, "stored activation"), (dres, "residual gradient")):
-        if t is not None and t.dtype != dz.dtype:
+        if t is not None and t.dtype != dz.dtype and not (t is act and t.dtype == torch.uint8):
             raise ValueError("the %s has the gradient's dtype" % nm)
-    ap, a_ld = _pm_operand(act, x, "stored activation", layout)
+    ap, a_ld, a_bits = _act_operand(act, x, layout)
     dp, d_ld = _pm_operand(dres, x, "residual gradient", layout)
     r = _row_ptrs(coef)
     t0 = _hbm_start()
     call("segk_bn_bwd_apply", _ptr(dz), _dt(dz), dz_ld, _ptr(x), _dt(x), x_ld, _ptr(dx), _dt(dx), dx_ld, layout, N,
          C, HW, r[0], r[1], r[2], r[3], 1 if relu else 0, _ptr(mask), ctypes.c_float(mask_scale), _ptr(gsums),
-         1 if eval_mode else 0, ap, a_ld, dp, d_ld, _stream())
+         1 if eval_mode else 0, ap, a_ld, a_bits, dp, d_ld, _stream())
     _hbm_stop("bn_bwd_apply", _nbytes(dz, x, dx, act, dres, mask), t0)
     return dx
 

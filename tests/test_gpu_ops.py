@@ -561,3 +561,16 @@ def test_bn_residual_relu_fused(ops, dtype, tol):
     assert relerr(sums[:C], br.grad) < tol
     xhat_scale = relerr(sums[C:2 * C] * coef[1].double(), gr.grad * coef[1].double())  # sum g*xhat = dgamma
     assert xhat_scale < tol
+    # the stored ReLU bit pattern (one bit per element beside the output) in place of the output itself: the same
+    # output, the bits of y > 0, and bit-identical backward results
+    bits = ops.relu_bits_like(y)
+    assert bits is not None and tuple(bits.shape) == (M, C // 8)
+    y2 = torch.empty_like(x)
+    ops.bn_apply(x, y2, coef, PM, True, res=res, relu_bits=bits)
+    assert torch.equal(y2, y)
+    want = ((y > 0).reshape(M, C // 8, 8).to(torch.int32) << torch.arange(8, device=y.device, dtype=torch.int32)).sum(-1)
+    assert torch.equal(bits.to(torch.int32), want)
+    sums2 = ops.bn_bwd_local_sums(g, x, coef, PM, True, act=bits)
+    dx2, dres2 = torch.empty_like(x), torch.empty_like(x)
+    ops.bn_bwd_apply(g, x, dx2, coef, sums2, PM, True, act=bits, dres=dres2)
+    assert torch.equal(sums2, sums) and torch.equal(dx2, dx) and torch.equal(dres2, dres)
