@@ -79,9 +79,18 @@ def main():
             w4.grad = None
             F.conv2d(x4, w4, padding=pad, dilation=dil).backward(g4)
         t_tb = graphed_us(both) - t_tf
+        # the two halves of PyTorch-ROCm's backward on their own
+        y4 = F.conv2d(x4, w4, padding=pad, dilation=dil).detach()
+
+        def half(mask):
+            return torch.ops.aten.convolution_backward(g4, x4.detach(), w4.detach(), None, [1, 1], [pad, pad], [dil, dil],
+                                                       False, [0, 0], 1, mask)
+        t_td = graphed_us(lambda: half([True, False, False]))
+        t_tw = graphed_us(lambda: half([False, True, False]))
         t_st = graphed_us(lambda: ops.bn_local_sums(out, 0))
         print("%-18s M=%6d | segk fwd+stats %6.1f dgrad(+pack) %6.1f wgrad %6.1f = %6.1f us | torch fwd %6.1f + stats %5.1f + bwd %6.1f "
-              "= %6.1f us" % (name, M, t_f, t_d, t_w, t_f + t_d + t_w, t_tf, t_st, t_tb, t_tf + t_st + t_tb), flush=True)
+              "(dgrad %5.1f, wgrad %5.1f alone) = %6.1f us" % (name, M, t_f, t_d, t_w, t_f + t_d + t_w, t_tf, t_st, t_tb, t_td, t_tw,
+                                                             t_tf + t_st + t_tb), flush=True)
 
 
 if __name__ == "__main__":
