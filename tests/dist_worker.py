@@ -97,7 +97,9 @@ GPU_N, GPU_K = 4, 7
 
 
 def gpu_case(device, images, sync, overlap_buckets=None, backwards=1):
-    """Head + a small SyncBN'd stem standing in for the feeder, one SGD-free step; returns loss, grads.
+    """Head + a small SyncBN'd stem standing in for the feeder (a strided convolution, then a dilated 3x3
+    convolution -> batch norm -> ReLU unit on the implicit-GEMM kernels, whose statistics come out of the
+    convolution's epilogue and are all-reduced like any other), one SGD-free step; returns loss, grads.
     overlap_buckets (MB): attach GradientBuckets(overlap=True) before backward and finish them (net.overlapped)."""
     from segk.modeling.aspp import build_aspp
     from segk.modeling.decoder import build_decoder
@@ -112,13 +114,18 @@ def gpu_case(device, images, sync, overlap_buckets=None, backwards=1):
             super().__init__()
             self.stem = nn.Conv2d(3, 320, 3, stride=4, padding=1, bias=False)
             self.stem_bn = BN(320)
+            self.mid = nn.Conv2d(320, 320, 3, padding=2, dilation=2, bias=False)
+            self.mid_bn = BN(320)
             self.low = nn.Conv2d(3, 24, 3, stride=2, padding=1, bias=False)
             self.low_bn = BN(24)
             self.aspp = build_aspp("mobilenet", 16, BN)
             self.decoder = build_decoder(GPU_K, "mobilenet", BN)
 
         def forward(self, img):
-            x = F.relu(self.stem_bn(self.stem(img)))
+            x = F.relu(self.stem_bn(self.stem(img))).contiguous(memory_format=torch.channels_last)
+            if not self.mid_bn.can_fuse_conv(self.mid, x):
+                raise RuntimeError("the 3x3 unit of this case must run on the implicit-GEMM kernels")
+            x = self.mid_bn.forward_conv_relu(self.mid, x)
             low = F.relu(self.low_bn(self.low(img)))
             y = self.decoder(self.aspp(x), low)
             return SF.interpolate_bilinear_ac(y, img.shape[2:])
