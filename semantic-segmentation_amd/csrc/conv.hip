@@ -1479,6 +1479,279 @@ __global__ __launch_bounds__(STAGES == 3 ? 512 : 256, (PX == 128 && STAGES == 1)
   conv_epilogue<TO, G>(p, acc, smem, wr, wc, lane, tid, co0, m0, mt, bz);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ring tile: 128 output channels x 160 pixels per workgroup, K steps of 64 channels through a ring of three LDS
+// stages, twelve wavefronts with fixed roles.  What the measurements behind it say (tools/micro/burst2.hip):
+//   * a CU pulls 64 B/clk through LDS-DMA when two bursts are in flight, 40 when it waits for each burst: one
+//     burst's latency (~440 cycles) has to be hidden behind the transfer of the next;
+//   * __syncthreads() is preceded by s_waitcnt vmcnt(0) (its release fence), which empties that pipeline at every
+//     barrier: the loops below use the bare s_barrier and counted vmcnt waits;
+//   * a wavefront's LDS reads queue behind its own LDS-DMA in flight (a ds_read_b128 issued after eight loads
+//     returns after ~435 cycles instead of ~100): wavefronts that load never read LDS in the K loop (tap offsets
+//     sit in lanes and are fetched with v_readlane), wavefronts that multiply never load;
+//   * every VALU instruction of a loading wavefront is 4 cycles in front of the next load: addresses are a
+//     per-step scalar base (buffer resource) plus per-lane offsets that only change with the segment, rows outside
+//     the image get an out-of-range offset (the buffer load then writes zeros), LDS destinations are scalar.
+// Wavefronts 0-3 load (9 one-KiB pieces each per step: 4 of the weight tile, 5 of the pixel tile) two steps ahead;
+// wavefronts 4-11 multiply (4 x 2, 32 channels x 80 pixels each: two wavefronts per SIMD cover each other's
+// fragment-read latency).  One barrier per step: the loads of step k have landed (each loader waits for its own
+// with vmcnt(9): step k+1 may still be in flight) and the multipliers have left step k-1, whose stage the loaders
+// refill with step k+2.
+constexpr int RING_PX = 160;
+constexpr int RING_STAGE_B = (128 + RING_PX) * 128;
+// STAGES = 3 with MW = 8 multiplying wavefronts is the form described above (110 KB of LDS, one workgroup per CU);
+// STAGES = 2 with MW = 4 (2 x 2, 64 channels x 80 pixels each, the loaders one step ahead) fits two workgroups per CU,
+// which then cover each other's prologue, epilogue and load latency on launches of many workgroups.
+
+__device__ __forceinline__ void bare_barrier() {
+  asm volatile("" ::: "memory");        // the compiler keeps memory operations on their side of the barrier
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+template <typename TO, int STAGES, int MW>
+// (second launch bound = wavefronts per SIMD: one workgroup per CU with three stages, two with two)
+__global__ __launch_bounds__(256 + 64 * MW, (STAGES == 3 ? 1 : 2) * (4 + MW) / 4) void conv_fwd_ring_kernel(const ConvDev p) {
+  typedef TileCfg<128, RING_PX, MW / 2, 2> G;
+  constexpr int BKB = 128, MI = G::MI, MJ = G::MJ;
+  constexpr int AHEAD = STAGES - 1;   // steps the loaders run ahead of the multipliers
+  constexpr int NB = RING_PX / 32;   // pixel pieces per loading wavefront
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 x ([A 128 rows][B 160 rows] x 128 B, swizzled)
+  __shared__ int ntaps_l[SEGK_MAX_SEG];
+  __shared__ unsigned int mask_l[2];
+  __shared__ int tap_a_l[SEGK_MAX_SEG * 9];    // per listed tap: byte offset of its weight slice ...
+  __shared__ int tap_b_l[SEGK_MAX_SEG * 9];    // ... and of its shifted pixel window
+  __shared__ int tap_dy_l[SEGK_MAX_SEG * 9];
+  __shared__ int tap_dx_l[SEGK_MAX_SEG * 9];
+
+  const int wave_all = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool loader = wave_all < 4;
+  const int wave = loader ? wave_all : wave_all - 4;
+  const int lane = threadIdx.x & 63;
+  unsigned tile;
+  {
+    const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u, xcd = blockIdx.x & 7u;
+    tile = xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3);
+  }
+  const int nt = tile % p.n_tiles;
+  const long long mt = tile / p.n_tiles;
+  const int co0 = nt * G::BCO;
+  const long long m0 = p.m_begin + mt * G::BPX;
+  const long long bz = blockIdx.y;
+
+  // loader geometry: piece q = i*4 + wave covers tile rows q*8 .. q*8+7; lane l -> row q*8 + (l>>3), LDS slot l&7,
+  // which holds source chunk (l&7) ^ (row&7)
+  const int lrow = lane >> 3;
+  const int lchunk = ((lane & 7) ^ lrow) << 4;
+  int wrow[4], ry[NB], rx[NB];
+  bool rvalid[NB];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int co = co0 + (i * 4 + wave) * 8 + lrow;
+    wrow[i] = (co < p.Cout ? co : p.Cout - 1) - co0;
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const long long m = m0 + (i * 4 + wave) * 8 + lrow;
+    rvalid[i] = loader && m < p.M;
+    const int rem = pixel_in_image(rvalid[i] ? m : 0, p.HW);
+    ry[i] = rem / p.W;
+    rx[i] = rem - ry[i] * p.W;
+  }
+
+  if (threadIdx.x < 2) mask_l[threadIdx.x] = 0u;
+  __syncthreads();
+  if (loader) {
+    unsigned long long mine = 0ull;
+    for (int sg = 0; sg < p.nseg; ++sg) {
+      const int R = p.seg[sg].R, dil = p.seg[sg].dil + (int)blockIdx.y * p.dil_step;
+      for (int tap = 0; tap < R * R; ++tap) {
+        const int dy = (tap / R - (R >> 1)) * dil, dx = (tap % R - (R >> 1)) * dil;
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+          any |= rvalid[i] && (unsigned)(ry[i] + dy) < (unsigned)p.H && (unsigned)(rx[i] + dx) < (unsigned)p.W;
+        if (any) mine |= 1ull << (sg * 9 + tap);
+      }
+    }
+    const unsigned int lo = (unsigned int)mine, hi = (unsigned int)(mine >> 32);
+    if (lo) atomicOr(&mask_l[0], lo);
+    if (hi) atomicOr(&mask_l[1], hi);
+  }
+  __syncthreads();
+  if (threadIdx.x < SEGK_MAX_SEG * 9) {
+    const unsigned long long all = ((unsigned long long)mask_l[1] << 32) | mask_l[0];
+    const int sg = threadIdx.x / 9, tap = threadIdx.x - sg * 9;
+    if (sg < p.nseg) {
+      const unsigned seg_bits = (unsigned)(all >> (sg * 9)) & 0x1ffu;
+      if (tap == 0) ntaps_l[sg] = __popc(seg_bits);
+      if ((seg_bits >> tap) & 1u) {
+        const SegDev& sd = p.seg[sg];
+        const int slot = sg * 9 + __popc(seg_bits & ((1u << tap) - 1u));
+        const int R = sd.R, dil = sd.dil + (int)blockIdx.y * p.dil_step;
+        const int dy = (tap / R - (R >> 1)) * dil, dx = (tap % R - (R >> 1)) * dil;
+        tap_a_l[slot] = (int)((long long)tap * sd.w_tap_b);
+        tap_b_l[slot] = (int)(((long long)dy * p.W + dx) * sd.in_ld_b);
+        tap_dy_l[slot] = dy;
+        tap_dx_l[slot] = dx;
+      }
+    }
+  }
+  __syncthreads();
+  int total = 0;
+  for (int sg = 0; sg < p.nseg; ++sg)
+    total += __builtin_amdgcn_readfirstlane(ntaps_l[sg]) * (p.seg[sg].ck_b / BKB);
+  // (the compiler's uniformity analysis loses track of values first read under the divergent branches above; the
+  // loops below must branch on scalars)
+  total = __builtin_amdgcn_readfirstlane(total);
+  if (p.abl & 16) total = 0;             // timing experiment: the fixed cost of a workgroup
+
+  f32x4 acc[MI][MJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (loader) {
+    int sg = -1, ti = 0, kc = 0, nkc = 0, ntap = 0;
+    int aoff[4], boff[NB];
+    int v_ta = 0, v_tb = 0;            // lane t: offsets of the t-th listed tap of the current segment
+    unsigned long long ok = 0ull;      // bit ti * NB + i: listed tap ti may read this lane's i-th pixel row
+    __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.seg[0].w, 0, 0, 0);
+    const char* bseg = nullptr;
+    int a_soff = 0;
+    const char* b_base = nullptr;
+    unsigned bits = 0u;
+    auto next_seg = [&]() {            // rare (at most SEGK_MAX_SEG times): LDS reads are fine here
+      ++sg;
+      while (__builtin_amdgcn_readfirstlane(ntaps_l[sg]) == 0) ++sg;
+      ntap = __builtin_amdgcn_readfirstlane(ntaps_l[sg]);
+      const SegDev& s = p.seg[sg];
+      nkc = s.ck_b / BKB;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) aoff[i] = wrow[i] * s.w_ld_b + lchunk;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) boff[i] = ((i * 4 + wave) * 8 + lrow) * (int)s.in_ld_b + lchunk;
+      arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(s.w + bz * s.w_batch_b + (long long)co0 * s.w_ld_b), 0, 0x7fffffff,
+                                                0x00020000);
+      bseg = s.in + bz * s.in_batch_b + m0 * s.in_ld_b;
+      v_ta = lane < ntap ? tap_a_l[sg * 9 + lane] : 0;
+      v_tb = lane < ntap ? tap_b_l[sg * 9 + lane] : 0;
+      ok = 0ull;
+      for (int t = 0; t < ntap; ++t) {
+        const int dy = tap_dy_l[sg * 9 + t], dx = tap_dx_l[sg * 9 + t];
+        unsigned m = 0u;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+          m |= (unsigned)(rvalid[i] && (unsigned)(ry[i] + dy) < (unsigned)p.H && (unsigned)(rx[i] + dx) < (unsigned)p.W) << i;
+        ok |= (unsigned long long)m << (t * NB);
+      }
+    };
+    auto set_step = [&]() {
+      const int ta = __builtin_amdgcn_readlane(v_ta, ti), tb = __builtin_amdgcn_readlane(v_tb, ti);
+      a_soff = ta + kc * BKB;
+      b_base = bseg + tb + kc * BKB;
+      bits = (unsigned)(ok >> (ti * NB));
+    };
+    auto advance = [&]() {
+      if (p.abl & 4) return;             // timing experiment: every step loads the first step's tiles
+      if (++ti >= ntap) {
+        ti = 0;
+        if (++kc >= nkc) {
+          kc = 0;
+          next_seg();
+        }
+      }
+      set_step();
+    };
+    auto issue = [&](int stage) {
+      char* const sa_w = smem + stage * RING_STAGE_B + wave * 1024;
+      char* const sb_w = sa_w + 128 * 128;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void_ptr)(sa_w + i * 4096), 16, aoff[i], a_soff, 0, 0);
+      // rows the tap may not read get an offset beyond the resource's range: the load writes zeros and touches no memory
+      const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(brsrc, (lds_void_ptr)(sb_w + i * 4096), 16,
+                                                 ((bits >> i) & 1u) ? boff[i] : (int)0x80000000, 0, 0, 0);
+    };
+    if (total > 0) {
+      next_seg();
+      set_step();
+      issue(0);
+      if (AHEAD == 2 && total > 1) {
+        advance();
+        issue(1);
+      }
+      int fill = AHEAD == 2 ? 2 : 1;     // stage of step st + AHEAD
+      for (int st = 0; st < total; ++st) {
+        // this wavefront's loads of step st have landed; with three stages those of step st + 1 may still be in flight
+        if (AHEAD == 2 && st + 1 < total) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bare_barrier();
+        if (st + AHEAD < total) {
+          advance();
+          issue(fill);
+          fill = fill == STAGES - 1 ? 0 : fill + 1;
+        }
+      }
+      bare_barrier();                    // the multipliers are done with the last step (their epilogue reuses the LDS)
+    }
+    if (p.stat) __syncthreads();         // the barrier inside the statistics part of the epilogue
+    return;
+  }
+
+  const int tid = (int)threadIdx.x - 256;   // index among the multiplying threads
+  const int wr = wave >> 1, wc = wave & 1;
+  if (total > 0) {
+    const int frow = lane & 15, fg = lane >> 4;
+    int stage = 0;
+    for (int st = 0; st < total; ++st) {
+      bare_barrier();
+      if (!(p.abl & 2)) {                // timing experiment: loads and barriers only
+        const char* a = smem + stage * RING_STAGE_B;
+        const char* b = a + 128 * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          u32x4 fb[MJ];
+#pragma unroll
+          for (int j = 0; j < MJ; ++j)
+            fb[j] = *reinterpret_cast<const u32x4*>(b + tile_off<BKB>(wc * (MJ * 16) + j * 16 + frow, ks * 4 + fg));
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            const u32x4 fa = *reinterpret_cast<const u32x4*>(a + tile_off<BKB>(wr * (MI * 16) + i * 16 + frow, ks * 4 + fg));
+#pragma unroll
+            for (int j = 0; j < MJ; ++j) Mma<bf16_t>::run(fa, fb[j], acc[i][j]);
+          }
+        }
+      }
+      stage = stage == STAGES - 1 ? 0 : stage + 1;
+    }
+    bare_barrier();
+  }
+  conv_epilogue<TO, G>(p, acc, smem, wr, wc, lane, tid, co0, m0, mt, bz);
+}
+
+template <typename TO, int STAGES, int MW>
+static int launch_ring(ConvDev& d, hipStream_t st, int batch, long long px_tiles) {
+  constexpr int lds = STAGES * RING_STAGE_B;
+  d.n_tiles = ceil_div(d.Cout, 128);
+  const long long blocks = px_tiles * d.n_tiles;
+  if (blocks >= 2147483647LL) {
+    set_error("conv: too many tiles");
+    return SEGK_INVALID_ARG;
+  }
+  static LdsConfigured configured;  // per instantiation
+  int rc = set_lds(conv_fwd_ring_kernel<TO, STAGES, MW>, lds, "conv_fwd_ring", configured);
+  if (rc != SEGK_OK) return rc;
+  conv_fwd_ring_kernel<TO, STAGES, MW><<<dim3((unsigned)blocks, (unsigned)batch), 256 + 64 * MW, lds, st>>>(d);
+  return SEGK_OK;
+}
+
 static int cu_count() {
   static int n = [] {
     int dev = 0, v = 0;
@@ -1600,10 +1873,36 @@ struct TilePlan {
   bool big;
   long long main_tiles;  // pixel tiles of the first launch
   bool tail;             // remaining pixels in a second, small-tile launch
+  int ring;              // form of the 128 x 160 ring tile (bf16 operands, 128-byte K rows), 0 = not used
 };
 
-static TilePlan plan_tiles(const ConvDev& d, bool wide, int batch) {
+// Which form of the ring tile serves a problem, 0 = none.  Measured against the one-stage tiles (rocprofv3 kernel
+// durations, batch 16): launches of at most one workgroup per CU take the three-stage form (ResNet layer-3 3x3 46 ->
+// 33 us, ASPP 1x1 45 -> 31, one dilated ASPP 3x3 256 -> 166), larger ones the two-stage form with two workgroups per
+// CU (decoder 3x3 514 -> 456 and 400 -> 385, its data gradients 395 -> 368, the ASPP data gradient 481 -> 453,
+// layer-4 3x3 109 -> 96).  Not for outputs of 64 channels or fewer (a 128-channel tile is mostly padding: decoder
+// 1x1 onto 48 channels 59 against 70) nor for fewer than eight K steps (data gradient of the ASPP projection,
+// four steps: 46 against 57): there the fixed cost of the larger workgroup is not won back.
+static int ring_form(const ConvDev& d, bool wide, bool bf16, int batch) {
+  if (!wide || !bf16) return 0;
+  static const char* e = experiment("SEGK_CONV_RING");
+  if (e) return e[0] >= '1' && e[0] <= '4' ? e[0] - '0' : 0;
+  long long steps = 0;
+  for (int s = 0; s < d.nseg; ++s) steps += (long long)d.seg[s].R * d.seg[s].R * (d.seg[s].ck_b / 128);
+  if (d.Cout <= 64 || steps < 8) return 0;
+  const long long blocks = ((d.M + RING_PX - 1) / RING_PX) * ceil_div(d.Cout, 128) * batch;
+  return blocks <= cu_count() ? 1 : 2;
+}
+
+static TilePlan plan_tiles(const ConvDev& d, bool wide, int batch, bool bf16) {
   TilePlan pl;
+  pl.ring = ring_form(d, wide, bf16, batch);
+  if (pl.ring) {
+    pl.big = false;
+    pl.tail = false;
+    pl.main_tiles = (d.M + RING_PX - 1) / RING_PX;
+    return pl;
+  }
   pl.big = use_big_tile(d, wide, batch);
   pl.tail = false;
   pl.main_tiles = (d.M + (pl.big ? TileBig::BPX : TileSmall::BPX) - 1) / (pl.big ? TileBig::BPX : TileSmall::BPX);
@@ -1698,7 +1997,7 @@ extern "C" int segk_conv_stat_rows(const segk_conv_args* a) {
     return SEGK_INVALID_ARG;
   ConvDev d;
   const bool wide = fill_dev(a, d);
-  return plan_stat_rows(d, plan_tiles(d, wide, a->batch > 1 ? a->batch : 1));
+  return plan_stat_rows(d, plan_tiles(d, wide, a->batch > 1 ? a->batch : 1, a->dtype == SEGK_BF16));
 }
 
 extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
@@ -1709,7 +2008,7 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
   const int batch = a->batch > 1 ? a->batch : 1;
   SEGK_REQUIRE(batch <= 65535 && (batch == 1 || (!a->bias && !a->img_bias)),
                "conv: batch=%d (biases are not batched)", batch);
-  const TilePlan plan = plan_tiles(d, wide, batch);
+  const TilePlan plan = plan_tiles(d, wide, batch, a->dtype == SEGK_BF16);
   const bool big = plan.big;
   d.stat_batch = (long long)plan_stat_rows(d, plan) * 2 * d.Cout;
   hipStream_t st = (hipStream_t)stream;
@@ -1739,6 +2038,21 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
     return SEGK_OK;
   }
 #endif
+  if (plan.ring) {
+    const int f = plan.ring;
+#define SEGK_RING(S, W) (a->out_dtype == SEGK_BF16 ? launch_ring<bf16_t, S, W>(d, st, batch, plan.main_tiles) \
+                                                   : launch_ring<float, S, W>(d, st, batch, plan.main_tiles))
+#ifdef SEGK_EXPERIMENTS
+    if (f == 3) rc = SEGK_RING(3, 4);
+    else if (f == 4) rc = SEGK_RING(2, 8);
+    else
+#endif
+    rc = f == 2 ? SEGK_RING(2, 4) : SEGK_RING(3, 8);
+#undef SEGK_RING
+    if (rc != SEGK_OK) return rc;
+    SEGK_CHECK_LAUNCH("conv_fwd");
+    return SEGK_OK;
+  }
 #define SEGK_LAUNCH(T, TO)                                                          \
   (big ? launch_fwd<T, 128, TO, TileBig>(d, st, batch)                              \
        : (wide ? launch_fwd<T, 128, TO, TileSmall>(d, st, batch) : launch_fwd<T, 64, TO, TileSmall>(d, st, batch)))

@@ -70,6 +70,17 @@ def main():
         ms = timeit(lambda: ops.conv_fwd(segs, n, 33, 33, 2048, out))
         fl = 2.0 * M * 2048 * 256 * 28
         print("dgrad %-20s M=%7d  %8.1f us  %7.1f TF nominal" % ("asppdgrad 4 segs", M, ms * 1e3, fl / ms / 1e9))
+    if not args.only or "asppbatch" in args.only:
+        # the three dilated ASPP branches in one launch (blockIdx.y = branch)
+        M = n * 33 * 33
+        x = torch.randn((M, 2048), device=dev).to(dt)
+        w = torch.randn((3, 256, 2048, 3, 3), device=dev) * 0.05
+        wp = torch.stack([ops.pack_weight(w[b], dt) for b in range(3)]).contiguous()
+        out = torch.empty((M, 1280), dtype=dt, device=dev)
+        ms = timeit(lambda: ops.conv_fwd([(x, wp, 3, 6)], n, 33, 33, 256, out[:, 256:], want_stats=True, batch=3,
+                                         dil_step=6, out_batch=256))
+        fl = 3 * 2.0 * M * 256 * 2048 * 9
+        print("fwd   %-20s M=%7d  %8.1f us  %7.1f TF nominal" % ("asppbatch 3 x 3x3", M, ms * 1e3, fl / ms / 1e9))
     wg = [("aspp 3x3 d6", 33, 2048, 256, 3, 6), ("aspp 3x3 d18", 33, 2048, 256, 3, 18), ("aspp proj", 33, 1280, 256, 1, 1),
           ("dec 3x3 304", 129, 320, 256, 3, 1), ("dec 3x3 256", 129, 256, 256, 3, 1), ("dec conv1", 129, 256, 48, 1, 1)]
     for name, H, cin, cout, R, dil in wg:
