@@ -65,6 +65,7 @@ struct ConvDev {
   double* stat;
   long long m_begin;     // first pixel of this launch (a problem may be cut into a main and a tail launch)
   long long stat_row0;   // statistic partial row of this launch's first pixel tile
+  int ring_tiles;        // ring tile: pixel tiles x output-channel tiles of the launch (workgroups may walk over several)
   int abl;               // timing experiments of the LDS-DMA tile (experiment builds only; results are garbage), a
                          // bit mask: 1 = every load reads the zero page, 2 = no fragment reads / MFMAs, 4 = no
                          // per-step address bookkeeping, 8 = no output stores, 16 = no K loop (fixed cost only)
@@ -1480,28 +1481,30 @@ __global__ __launch_bounds__(STAGES == 3 ? 512 : 256, (PX == 128 && STAGES == 1)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Ring tile: 128 output channels x 160 pixels per workgroup, K steps of 64 channels through a ring of three LDS
-// stages, twelve wavefronts with fixed roles.  What the measurements behind it say (tools/micro/burst2.hip):
+// Ring tile: 128 output channels x 160 pixels per tile, K steps of 64 channels through a ring of LDS stages,
+// wavefronts with fixed roles, persistent workgroups.  What the measurements behind it say (tools/micro/burst2.hip):
 //   * a CU pulls 64 B/clk through LDS-DMA when two bursts are in flight, 40 when it waits for each burst: one
 //     burst's latency (~440 cycles) has to be hidden behind the transfer of the next;
 //   * __syncthreads() is preceded by s_waitcnt vmcnt(0) (its release fence), which empties that pipeline at every
 //     barrier: the loops below use the bare s_barrier and counted vmcnt waits;
 //   * a wavefront's LDS reads queue behind its own LDS-DMA in flight (a ds_read_b128 issued after eight loads
-//     returns after ~435 cycles instead of ~100): wavefronts that load never read LDS in the K loop (tap offsets
-//     sit in lanes and are fetched with v_readlane), wavefronts that multiply never load;
-//   * every VALU instruction of a loading wavefront is 4 cycles in front of the next load: addresses are a
-//     per-step scalar base (buffer resource) plus per-lane offsets that only change with the segment, rows outside
-//     the image get an out-of-range offset (the buffer load then writes zeros), LDS destinations are scalar.
-// Wavefronts 0-3 load (9 one-KiB pieces each per step: 4 of the weight tile, 5 of the pixel tile) two steps ahead;
-// wavefronts 4-11 multiply (4 x 2, 32 channels x 80 pixels each: two wavefronts per SIMD cover each other's
-// fragment-read latency).  One barrier per step: the loads of step k have landed (each loader waits for its own
-// with vmcnt(9): step k+1 may still be in flight) and the multipliers have left step k-1, whose stage the loaders
-// refill with step k+2.
+//     returns after ~435 cycles instead of ~100): wavefronts that load never read LDS (tap offsets sit in lanes and
+//     are fetched with v_readlane), wavefronts that multiply never load;
+//   * addresses are a per-step scalar base (buffer resource) plus per-lane offsets that only change with the
+//     segment; rows outside the image get an out-of-range offset (the buffer load then writes zeros and touches no
+//     memory); LDS destinations are scalar.
+// Wavefronts 0-3 load (9 one-KiB pieces each per step: 4 of the weight tile, 5 of the pixel tile) STAGES - 1 steps
+// ahead; the others multiply.  One barrier per step: the loads of step k have landed (each loader waits for its own
+// with a counted vmcnt: later steps may still be in flight) and the multipliers have left step k-1, whose stage the
+// loaders refill.  Nothing else is shared: every wavefront derives the tile's tap list itself (which of the 3 x 3
+// taps reach into the image from any of the tile's pixels, by wavefront-wide votes), so there is no table in LDS and
+// no barrier outside the K loop, and a workgroup that walks over several tiles loads the first steps of the next tile
+// while its multipliers still store the previous one: the fixed cost of a tile (about a third of a 36-step tile)
+// disappears behind the K loops of its neighbours.
+//   STAGES = 3, MW = 8 multiplying wavefronts (4 x 2, 32 channels x 80 pixels each): 110 KB of LDS, one workgroup
+//   per CU; STAGES = 2, MW = 4 (2 x 2, 64 x 80 each): two workgroups per CU.
 constexpr int RING_PX = 160;
 constexpr int RING_STAGE_B = (128 + RING_PX) * 128;
-// STAGES = 3 with MW = 8 multiplying wavefronts is the form described above (110 KB of LDS, one workgroup per CU);
-// STAGES = 2 with MW = 4 (2 x 2, 64 channels x 80 pixels each, the loaders one step ahead) fits two workgroups per CU,
-// which then cover each other's prologue, epilogue and load latency on launches of many workgroups.
 
 __device__ __forceinline__ void bare_barrier() {
   asm volatile("" ::: "memory");        // the compiler keeps memory operations on their side of the barrier
@@ -1511,208 +1514,224 @@ __device__ __forceinline__ void bare_barrier() {
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
+// bits of the 3 x 3 taps (index ty * 3 + tx) that pixel (y, x) may read under dilation d; the centre always
+__device__ __forceinline__ unsigned taps_of_pixel(int y, int x, int d, int H, int W) {
+  const unsigned xb = (x - d >= 0 ? 1u : 0u) | 2u | (x + d < W ? 4u : 0u);
+  return (y - d >= 0 ? xb : 0u) | (xb << 3) | (y + d < H ? xb << 6 : 0u);
+}
+
 template <typename TO, int STAGES, int MW>
 // (second launch bound = wavefronts per SIMD: one workgroup per CU with three stages, two with two)
 __global__ __launch_bounds__(256 + 64 * MW, (STAGES == 3 ? 1 : 2) * (4 + MW) / 4) void conv_fwd_ring_kernel(const ConvDev p) {
   typedef TileCfg<128, RING_PX, MW / 2, 2> G;
   constexpr int BKB = 128, MI = G::MI, MJ = G::MJ;
+  constexpr int NB = RING_PX / 32;    // pixel pieces per loading wavefront
   constexpr int AHEAD = STAGES - 1;   // steps the loaders run ahead of the multipliers
-  constexpr int NB = RING_PX / 32;   // pixel pieces per loading wavefront
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 x ([A 128 rows][B 160 rows] x 128 B, swizzled)
-  __shared__ int ntaps_l[SEGK_MAX_SEG];
-  __shared__ unsigned int mask_l[2];
-  __shared__ int tap_a_l[SEGK_MAX_SEG * 9];    // per listed tap: byte offset of its weight slice ...
-  __shared__ int tap_b_l[SEGK_MAX_SEG * 9];    // ... and of its shifted pixel window
-  __shared__ int tap_dy_l[SEGK_MAX_SEG * 9];
-  __shared__ int tap_dx_l[SEGK_MAX_SEG * 9];
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // STAGES x ([A 128 rows][B 160 rows] x 128 B, swizzled)
 
   const int wave_all = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const bool loader = wave_all < 4;
   const int wave = loader ? wave_all : wave_all - 4;
   const int lane = threadIdx.x & 63;
-  unsigned tile;
-  {
-    const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u, xcd = blockIdx.x & 7u;
-    tile = xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3);
-  }
-  const int nt = tile % p.n_tiles;
-  const long long mt = tile / p.n_tiles;
-  const int co0 = nt * G::BCO;
-  const long long m0 = p.m_begin + mt * G::BPX;
   const long long bz = blockIdx.y;
+  const int nseg = __builtin_amdgcn_readfirstlane(p.nseg);
+  const unsigned ntiles = (unsigned)__builtin_amdgcn_readfirstlane(p.ring_tiles);
 
-  // loader geometry: piece q = i*4 + wave covers tile rows q*8 .. q*8+7; lane l -> row q*8 + (l>>3), LDS slot l&7,
-  // which holds source chunk (l&7) ^ (row&7)
-  const int lrow = lane >> 3;
-  const int lchunk = ((lane & 7) ^ lrow) << 4;
-  int wrow[4], ry[NB], rx[NB];
-  bool rvalid[NB];
+  // The listed taps of a tile, per segment, and its number of K steps: the same in every wavefront.  Lane l looks
+  // at tile rows l, l + 64 and l + 128.
+  auto tile_taps = [&](long long m0, unsigned (&seg_bits)[SEGK_MAX_SEG]) -> int {
+    int y[3], x[3];
+    bool v[3];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int co = co0 + (i * 4 + wave) * 8 + lrow;
-    wrow[i] = (co < p.Cout ? co : p.Cout - 1) - co0;
-  }
+    for (int k = 0; k < 3; ++k) {
+      const int r = lane + 64 * k;
+      const long long m = m0 + r;
+      v[k] = r < RING_PX && m < p.M;
+      const int rem = pixel_in_image(v[k] ? m : 0, p.HW);
+      y[k] = rem / p.W;
+      x[k] = rem - y[k] * p.W;
+    }
+    int total = 0;
 #pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    const long long m = m0 + (i * 4 + wave) * 8 + lrow;
-    rvalid[i] = loader && m < p.M;
-    const int rem = pixel_in_image(rvalid[i] ? m : 0, p.HW);
-    ry[i] = rem / p.W;
-    rx[i] = rem - ry[i] * p.W;
-  }
-
-  if (threadIdx.x < 2) mask_l[threadIdx.x] = 0u;
-  __syncthreads();
-  if (loader) {
-    unsigned long long mine = 0ull;
-    for (int sg = 0; sg < p.nseg; ++sg) {
-      const int R = p.seg[sg].R, dil = p.seg[sg].dil + (int)blockIdx.y * p.dil_step;
-      for (int tap = 0; tap < R * R; ++tap) {
-        const int dy = (tap / R - (R >> 1)) * dil, dx = (tap % R - (R >> 1)) * dil;
-        bool any = false;
+    for (int sg = 0; sg < SEGK_MAX_SEG; ++sg) {
+      seg_bits[sg] = 0u;
+      if (sg < nseg) {
+        const int R = p.seg[sg].R, d = p.seg[sg].dil + (int)blockIdx.y * p.dil_step;
+        unsigned any = 0u;
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
-          any |= rvalid[i] && (unsigned)(ry[i] + dy) < (unsigned)p.H && (unsigned)(rx[i] + dx) < (unsigned)p.W;
-        if (any) mine |= 1ull << (sg * 9 + tap);
+        for (int k = 0; k < 3; ++k)
+          if (v[k]) any |= R == 1 ? 1u : taps_of_pixel(y[k], x[k], d, p.H, p.W);
+        unsigned bits = 0u;
+        for (int t = 0; t < R * R; ++t)
+          if (__builtin_amdgcn_ballot_w64((any >> t) & 1u) != 0ull) bits |= 1u << t;
+        seg_bits[sg] = __builtin_amdgcn_readfirstlane(bits);
+        total += __popc(bits) * (p.seg[sg].ck_b / BKB);
       }
     }
-    const unsigned int lo = (unsigned int)mine, hi = (unsigned int)(mine >> 32);
-    if (lo) atomicOr(&mask_l[0], lo);
-    if (hi) atomicOr(&mask_l[1], hi);
-  }
-  __syncthreads();
-  if (threadIdx.x < SEGK_MAX_SEG * 9) {
-    const unsigned long long all = ((unsigned long long)mask_l[1] << 32) | mask_l[0];
-    const int sg = threadIdx.x / 9, tap = threadIdx.x - sg * 9;
-    if (sg < p.nseg) {
-      const unsigned seg_bits = (unsigned)(all >> (sg * 9)) & 0x1ffu;
-      if (tap == 0) ntaps_l[sg] = __popc(seg_bits);
-      if ((seg_bits >> tap) & 1u) {
-        const SegDev& sd = p.seg[sg];
-        const int slot = sg * 9 + __popc(seg_bits & ((1u << tap) - 1u));
-        const int R = sd.R, dil = sd.dil + (int)blockIdx.y * p.dil_step;
-        const int dy = (tap / R - (R >> 1)) * dil, dx = (tap % R - (R >> 1)) * dil;
-        tap_a_l[slot] = (int)((long long)tap * sd.w_tap_b);
-        tap_b_l[slot] = (int)(((long long)dy * p.W + dx) * sd.in_ld_b);
-        tap_dy_l[slot] = dy;
-        tap_dx_l[slot] = dx;
-      }
-    }
-  }
-  __syncthreads();
-  int total = 0;
-  for (int sg = 0; sg < p.nseg; ++sg)
-    total += __builtin_amdgcn_readfirstlane(ntaps_l[sg]) * (p.seg[sg].ck_b / BKB);
-  // (the compiler's uniformity analysis loses track of values first read under the divergent branches above; the
-  // loops below must branch on scalars)
-  total = __builtin_amdgcn_readfirstlane(total);
-  if (p.abl & 16) total = 0;             // timing experiment: the fixed cost of a workgroup
-
-  f32x4 acc[MI][MJ];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    total = __builtin_amdgcn_readfirstlane(total);
+    return (p.abl & 16) ? 0 : total;     // timing experiment: the fixed cost of a tile
+  };
+  // virtual block -> tile: each XCD (virtual blocks with the same index modulo 8; the grid is a multiple of 8) walks
+  // over a contiguous run of tiles, so that the output-channel tiles of one pixel tile and neighbouring pixel tiles
+  // (which share the rows the 3 x 3 taps reach into) meet in the same L2
+  auto tile_of = [&](unsigned v) -> unsigned {
+    const unsigned q = ntiles >> 3, r = ntiles & 7u, xcd = v & 7u;
+    return xcd * q + (xcd < r ? xcd : r) + (v >> 3);
+  };
+  // (v >> 3 exceeds an XCD's run only for virtual blocks past the end, which the loops below never reach: the run of
+  // XCD x holds q + (x < r) tiles and v < ntiles rounded up to the grid stride is filtered by in_range)
+  auto in_range = [&](unsigned v) -> bool {
+    const unsigned q = ntiles >> 3, r = ntiles & 7u, xcd = v & 7u;
+    return (v >> 3) < q + (xcd < r ? 1u : 0u);
+  };
 
   if (loader) {
-    int sg = -1, ti = 0, kc = 0, nkc = 0, ntap = 0;
-    int aoff[4], boff[NB];
-    int v_ta = 0, v_tb = 0;            // lane t: offsets of the t-th listed tap of the current segment
-    unsigned long long ok = 0ull;      // bit ti * NB + i: listed tap ti may read this lane's i-th pixel row
-    __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.seg[0].w, 0, 0, 0);
-    const char* bseg = nullptr;
-    int a_soff = 0;
-    const char* b_base = nullptr;
-    unsigned bits = 0u;
-    auto next_seg = [&]() {            // rare (at most SEGK_MAX_SEG times): LDS reads are fine here
-      ++sg;
-      while (__builtin_amdgcn_readfirstlane(ntaps_l[sg]) == 0) ++sg;
-      ntap = __builtin_amdgcn_readfirstlane(ntaps_l[sg]);
-      const SegDev& s = p.seg[sg];
-      nkc = s.ck_b / BKB;
+    const int lrow = lane >> 3;
+    const int lchunk = ((lane & 7) ^ lrow) << 4;   // piece rows are 8-aligned: row & 7 == lrow
+    int fill = 0;                                  // stage of the next step to issue
+    for (unsigned v = blockIdx.x; in_range(v); v += gridDim.x) {
+      const unsigned tile = tile_of(v);
+      const int co0 = (int)(tile % (unsigned)p.n_tiles) * G::BCO;
+      const long long m0 = p.m_begin + (long long)(tile / (unsigned)p.n_tiles) * G::BPX;
+      unsigned seg_bits[SEGK_MAX_SEG];
+      const int total = tile_taps(m0, seg_bits);
+      // piece q = i*4 + wave covers tile rows q*8 .. q*8+7; lane l -> row q*8 + (l>>3), LDS slot l&7, which holds
+      // source chunk (l&7) ^ (row&7)
+      int wrow[4], ry[NB], rx[NB];
+      bool rvalid[NB];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) aoff[i] = wrow[i] * s.w_ld_b + lchunk;
-#pragma unroll
-      for (int i = 0; i < NB; ++i) boff[i] = ((i * 4 + wave) * 8 + lrow) * (int)s.in_ld_b + lchunk;
-      arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(s.w + bz * s.w_batch_b + (long long)co0 * s.w_ld_b), 0, 0x7fffffff,
-                                                0x00020000);
-      bseg = s.in + bz * s.in_batch_b + m0 * s.in_ld_b;
-      v_ta = lane < ntap ? tap_a_l[sg * 9 + lane] : 0;
-      v_tb = lane < ntap ? tap_b_l[sg * 9 + lane] : 0;
-      ok = 0ull;
-      for (int t = 0; t < ntap; ++t) {
-        const int dy = tap_dy_l[sg * 9 + t], dx = tap_dx_l[sg * 9 + t];
-        unsigned m = 0u;
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-          m |= (unsigned)(rvalid[i] && (unsigned)(ry[i] + dy) < (unsigned)p.H && (unsigned)(rx[i] + dx) < (unsigned)p.W) << i;
-        ok |= (unsigned long long)m << (t * NB);
+      for (int i = 0; i < 4; ++i) {
+        const int co = co0 + (i * 4 + wave) * 8 + lrow;
+        wrow[i] = (co < p.Cout ? co : p.Cout - 1) - co0;
       }
-    };
-    auto set_step = [&]() {
-      const int ta = __builtin_amdgcn_readlane(v_ta, ti), tb = __builtin_amdgcn_readlane(v_tb, ti);
-      a_soff = ta + kc * BKB;
-      b_base = bseg + tb + kc * BKB;
-      bits = (unsigned)(ok >> (ti * NB));
-    };
-    auto advance = [&]() {
-      if (p.abl & 4) return;             // timing experiment: every step loads the first step's tiles
-      if (++ti >= ntap) {
-        ti = 0;
-        if (++kc >= nkc) {
-          kc = 0;
-          next_seg();
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const long long m = m0 + (i * 4 + wave) * 8 + lrow;
+        rvalid[i] = m < p.M;
+        const int rem = pixel_in_image(rvalid[i] ? m : 0, p.HW);
+        ry[i] = rem / p.W;
+        rx[i] = rem - ry[i] * p.W;
+      }
+      int sg = -1, ti = 0, kc = 0, nkc = 0, ntap = 0;
+      int aoff[4], boff[NB];
+      int v_tap = 0, v_ta = 0, v_tb = 0;   // lane t: index and operand offsets of the t-th listed tap of the segment
+      unsigned long long ok = 0ull;        // bit 9 * i + tap: the tap may read this lane's i-th pixel row
+      __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.seg[0].w, 0, 0, 0);
+      const char* bseg = nullptr;
+      int a_soff = 0;
+      const char* b_base = nullptr;
+      int voff[NB];
+      auto next_seg = [&]() {              // at most SEGK_MAX_SEG times per tile
+        unsigned bits = 0u;
+        do {
+          ++sg;
+          // (readfirstlane: the compiler's uniformity analysis loses these values, and a resource descriptor it takes
+          // for divergent costs a readfirstlane loop around every load)
+          bits = __builtin_amdgcn_readfirstlane(sg == 0 ? seg_bits[0] : sg == 1 ? seg_bits[1] : sg == 2 ? seg_bits[2] : seg_bits[3]);
+        } while (bits == 0u);
+        sg = __builtin_amdgcn_readfirstlane(sg);
+        ntap = __popc(bits);
+        const SegDev& s = p.seg[sg];
+        const int R = s.R, d = s.dil + (int)blockIdx.y * p.dil_step;
+        nkc = s.ck_b / BKB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aoff[i] = wrow[i] * s.w_ld_b + lchunk;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) boff[i] = ((i * 4 + wave) * 8 + lrow) * (int)s.in_ld_b + lchunk;
+        arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(s.w + bz * s.w_batch_b + (long long)co0 * s.w_ld_b), 0, 0x7fffffff,
+                                                  0x00020000);
+        bseg = s.in + bz * s.in_batch_b + m0 * s.in_ld_b;
+        // lane l takes the l-th listed tap
+        int tap = 0, seen = 0;
+        for (int t = 0; t < R * R; ++t) {
+          const bool listed = (bits >> t) & 1u;
+          if (listed && seen == lane) tap = t;
+          seen += listed ? 1 : 0;
         }
-      }
-      set_step();
-    };
-    auto issue = [&](int stage) {
-      char* const sa_w = smem + stage * RING_STAGE_B + wave * 1024;
-      char* const sb_w = sa_w + 128 * 128;
+        const int dy = R == 1 ? 0 : (tap / 3 - 1) * d, dx = R == 1 ? 0 : (tap % 3 - 1) * d;
+        v_tap = tap;
+        v_ta = (int)((long long)tap * s.w_tap_b);
+        v_tb = (int)(((long long)dy * p.W + dx) * s.in_ld_b);
+        ok = 0ull;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void_ptr)(sa_w + i * 4096), 16, aoff[i], a_soff, 0, 0);
-      // rows the tap may not read get an offset beyond the resource's range: the load writes zeros and touches no memory
-      const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, 0x7fffffff, 0x00020000);
+        for (int i = 0; i < NB; ++i) {
+          const unsigned m9 = !rvalid[i] ? 0u : R == 1 ? 1u : taps_of_pixel(ry[i], rx[i], d, p.H, p.W);
+          ok |= (unsigned long long)m9 << (9 * i);
+        }
+      };
+      auto set_step = [&]() {
+        const int tap = __builtin_amdgcn_readlane(v_tap, ti);
+        a_soff = __builtin_amdgcn_readlane(v_ta, ti) + kc * BKB;
+        b_base = bseg + __builtin_amdgcn_readlane(v_tb, ti) + kc * BKB;
+        const unsigned long long sh = ok >> tap;
+        // rows the tap may not read get an offset beyond the resource's range: the load writes zeros, touches no memory
 #pragma unroll
-      for (int i = 0; i < NB; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(brsrc, (lds_void_ptr)(sb_w + i * 4096), 16,
-                                                 ((bits >> i) & 1u) ? boff[i] : (int)0x80000000, 0, 0, 0);
-    };
-    if (total > 0) {
-      next_seg();
-      set_step();
-      issue(0);
-      if (AHEAD == 2 && total > 1) {
-        advance();
-        issue(1);
-      }
-      int fill = AHEAD == 2 ? 2 : 1;     // stage of step st + AHEAD
-      for (int st = 0; st < total; ++st) {
-        // this wavefront's loads of step st have landed; with three stages those of step st + 1 may still be in flight
-        if (AHEAD == 2 && st + 1 < total) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        bare_barrier();
-        if (st + AHEAD < total) {
+        for (int i = 0; i < NB; ++i) voff[i] = ((sh >> (9 * i)) & 1ull) ? boff[i] : (int)0x80000000;
+      };
+      auto advance = [&]() {
+        if (p.abl & 4) return;             // timing experiment: every step loads the first step's tiles
+        if (++ti >= ntap) {
+          ti = 0;
+          if (++kc >= nkc) {
+            kc = 0;
+            next_seg();
+          }
+        }
+        set_step();
+      };
+      auto issue = [&]() {
+        char* const sa_w = smem + fill * RING_STAGE_B + wave * 1024;
+        char* const sb_w = sa_w + 128 * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void_ptr)(sa_w + i * 4096), 16, aoff[i], a_soff, 0, 0);
+        const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(brsrc, (lds_void_ptr)(sb_w + i * 4096), 16, voff[i], 0, 0, 0);
+        fill = fill == STAGES - 1 ? 0 : fill + 1;
+      };
+      if (total > 0) {
+        next_seg();
+        set_step();
+        issue();
+        if (AHEAD == 2 && total > 1) {
           advance();
-          issue(fill);
-          fill = fill == STAGES - 1 ? 0 : fill + 1;
+          issue();
+        }
+        for (int st = 0; st < total; ++st) {
+          // this wavefront's loads of step st have landed; with three stages those of step st + 1 may be in flight
+          if (AHEAD == 2 && st + 1 < total) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          bare_barrier();
+          if (st + AHEAD < total) {
+            advance();
+            issue();
+          }
         }
       }
-      bare_barrier();                    // the multipliers are done with the last step (their epilogue reuses the LDS)
     }
-    if (p.stat) __syncthreads();         // the barrier inside the statistics part of the epilogue
     return;
   }
 
-  const int tid = (int)threadIdx.x - 256;   // index among the multiplying threads
   const int wr = wave >> 1, wc = wave & 1;
-  if (total > 0) {
-    const int frow = lane & 15, fg = lane >> 4;
-    int stage = 0;
+  const int frow = lane & 15, fg = lane >> 4;
+  int stage = 0;
+  for (unsigned v = blockIdx.x; in_range(v); v += gridDim.x) {
+    const unsigned tile = tile_of(v);
+    const int co0 = (int)(tile % (unsigned)p.n_tiles) * G::BCO;
+    const long long mt = tile / (unsigned)p.n_tiles;
+    const long long m0 = p.m_begin + mt * G::BPX;
+    unsigned seg_bits[SEGK_MAX_SEG];
+    const int total = tile_taps(m0, seg_bits);
+    f32x4 acc[MI][MJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int st = 0; st < total; ++st) {
       bare_barrier();
-      if (!(p.abl & 2)) {                // timing experiment: loads and barriers only
+      if (!(p.abl & 2)) {                  // timing experiment: loads and barriers only
         const char* a = smem + stage * RING_STAGE_B;
         const char* b = a + 128 * 128;
 #pragma unroll
@@ -1731,26 +1750,69 @@ __global__ __launch_bounds__(256 + 64 * MW, (STAGES == 3 ? 1 : 2) * (4 + MW) / 4
       }
       stage = stage == STAGES - 1 ? 0 : stage + 1;
     }
-    bare_barrier();
+
+    // Epilogue without LDS or barriers (the loaders are already filling the ring for the next tile): a wavefront's
+    // statistics go to a partial row of its own (two rows per pixel tile, one per 80-pixel half).
+    // acc[i][j][r] = out[pixel = wc*MJ*16 + j*16 + (lane&15)][co = wr*MI*16 + i*16 + (lane>>4)*4 + r]
+    if (p.stat) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        double sv[4], qv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double sum = 0.0, sq = 0.0;
+#pragma unroll
+          for (int j = 0; j < MJ; ++j) {
+            const double t = (double)acc[i][j][r];
+            sum += t;
+            sq = fma(t, t, sq);
+          }
+          sv[r] = row16_sum(sum);
+          qv[r] = row16_sum(sq);
+        }
+        if (frow == 0) {
+          double* row = p.stat + bz * p.stat_batch + (size_t)((p.stat_row0 + mt) * 2 + wc) * 2 * p.Cout;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = co0 + wr * (MI * 16) + i * 16 + fg * 4 + r;
+            if (co < p.Cout) {
+              row[co] = sv[r];
+              row[p.Cout + co] = qv[r];
+            }
+          }
+        }
+      }
+    }
+    if (p.abl & 8) continue;               // timing experiment: no output stores
+    const int cpad = (p.Cout + 3) & ~3;
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {
+      const long long m = m0 + wc * (MJ * 16) + j * 16 + frow;
+      if (m >= p.M) continue;
+      const float* ib = p.img_bias ? p.img_bias + (m / p.HW) * p.Cout : nullptr;
+      char* orow = p.out + bz * p.out_batch_b + (size_t)m * p.out_ld * sizeof(TO);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int c = co0 + wr * (MI * 16) + i * 16 + fg * 4;
+        if (c >= cpad) continue;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float t = acc[i][j][r];
+          if (c + r < p.Cout) {
+            if (p.bias) t += p.bias[c + r];
+            if (ib) t += ib[c + r];
+          } else {
+            t = 0.f;
+          }
+          o[r] = t;
+        }
+        store_out4<TO>(orow + (size_t)c * sizeof(TO), o);
+      }
+    }
   }
-  conv_epilogue<TO, G>(p, acc, smem, wr, wc, lane, tid, co0, m0, mt, bz);
 }
 
-template <typename TO, int STAGES, int MW>
-static int launch_ring(ConvDev& d, hipStream_t st, int batch, long long px_tiles) {
-  constexpr int lds = STAGES * RING_STAGE_B;
-  d.n_tiles = ceil_div(d.Cout, 128);
-  const long long blocks = px_tiles * d.n_tiles;
-  if (blocks >= 2147483647LL) {
-    set_error("conv: too many tiles");
-    return SEGK_INVALID_ARG;
-  }
-  static LdsConfigured configured;  // per instantiation
-  int rc = set_lds(conv_fwd_ring_kernel<TO, STAGES, MW>, lds, "conv_fwd_ring", configured);
-  if (rc != SEGK_OK) return rc;
-  conv_fwd_ring_kernel<TO, STAGES, MW><<<dim3((unsigned)blocks, (unsigned)batch), 256 + 64 * MW, lds, st>>>(d);
-  return SEGK_OK;
-}
 
 static int cu_count() {
   static int n = [] {
@@ -1761,6 +1823,31 @@ static int cu_count() {
     return v;
   }();
   return n;
+}
+
+// The grid of a ring launch: every tile its own workgroup while they all fit on the chip at once, otherwise as many
+// workgroups as fit (a multiple of 8: one run of tiles per XCD), each walking over several tiles.
+template <typename TO, int STAGES, int MW>
+static int launch_ring(ConvDev& d, hipStream_t st, int batch, long long px_tiles) {
+  constexpr int lds = STAGES * RING_STAGE_B;
+  d.n_tiles = ceil_div(d.Cout, 128);
+  const long long tiles = px_tiles * d.n_tiles;
+  if (tiles >= 2147483647LL) {
+    set_error("conv: too many tiles");
+    return SEGK_INVALID_ARG;
+  }
+  d.ring_tiles = (int)tiles;
+  const long long slots = (long long)cu_count() * (STAGES == 3 ? 1 : 2);
+  long long grid = (tiles + 7) / 8 * 8;
+  if (grid * batch > slots) {
+    grid = slots / batch / 8 * 8;
+    if (grid < 8) grid = 8;
+  }
+  static LdsConfigured configured;  // per instantiation
+  int rc = set_lds(conv_fwd_ring_kernel<TO, STAGES, MW>, lds, "conv_fwd_ring", configured);
+  if (rc != SEGK_OK) return rc;
+  conv_fwd_ring_kernel<TO, STAGES, MW><<<dim3((unsigned)grid, (unsigned)batch), 256 + 64 * MW, lds, st>>>(d);
+  return SEGK_OK;
 }
 
 // px_tiles < 0: every pixel tile from d.m_begin to the end
@@ -1876,22 +1963,19 @@ struct TilePlan {
   int ring;              // form of the 128 x 160 ring tile (bf16 operands, 128-byte K rows), 0 = not used
 };
 
-// Which form of the ring tile serves a problem, 0 = none.  Measured against the one-stage tiles (rocprofv3 kernel
-// durations, batch 16): launches of at most one workgroup per CU take the three-stage form (ResNet layer-3 3x3 46 ->
-// 33 us, ASPP 1x1 45 -> 31, one dilated ASPP 3x3 256 -> 166), larger ones the two-stage form with two workgroups per
-// CU (decoder 3x3 514 -> 456 and 400 -> 385, its data gradients 395 -> 368, the ASPP data gradient 481 -> 453,
-// layer-4 3x3 109 -> 96).  Not for outputs of 64 channels or fewer (a 128-channel tile is mostly padding: decoder
-// 1x1 onto 48 channels 59 against 70) nor for fewer than eight K steps (data gradient of the ASPP projection,
-// four steps: 46 against 57): there the fixed cost of the larger workgroup is not won back.
+// Which form of the ring tile serves a problem, 0 = none: every convolution with bf16 operands and 128-byte K rows.
+// Launches whose tiles all fit on the chip at once (one workgroup per CU) and batched launches take the three-stage
+// form, larger ones the two-stage form with two workgroups per CU.  Kernel durations (rocprofv3, batch 16) against
+// the one-stage LDS-DMA tiles they replace: ResNet layer-3 3x3 46 -> 28 us, layer-4 3x3 109 -> 86, ASPP 1x1 45 -> 27,
+// one dilated ASPP 3x3 256 -> 157, the three of them in one launch 555 -> 517, decoder 3x3 514 -> 424 and 400 -> 365,
+// their data gradients 540 -> 472 and 395 -> 352, the ASPP data gradient (four segments) 481 -> 404, decoder 1x1
+// onto 48 channels 59 -> 55.
 static int ring_form(const ConvDev& d, bool wide, bool bf16, int batch) {
   if (!wide || !bf16) return 0;
   static const char* e = experiment("SEGK_CONV_RING");
   if (e) return e[0] >= '1' && e[0] <= '4' ? e[0] - '0' : 0;
-  long long steps = 0;
-  for (int s = 0; s < d.nseg; ++s) steps += (long long)d.seg[s].R * d.seg[s].R * (d.seg[s].ck_b / 128);
-  if (d.Cout <= 64 || steps < 8) return 0;
   const long long blocks = ((d.M + RING_PX - 1) / RING_PX) * ceil_div(d.Cout, 128) * batch;
-  return blocks <= cu_count() ? 1 : 2;
+  return blocks <= cu_count() || batch > 1 ? 1 : 2;
 }
 
 static TilePlan plan_tiles(const ConvDev& d, bool wide, int batch, bool bf16) {
@@ -1922,6 +2006,7 @@ static TilePlan plan_tiles(const ConvDev& d, bool wide, int batch, bool bf16) {
 }
 
 static int plan_stat_rows(const ConvDev& d, const TilePlan& pl) {
+  if (pl.ring) return (int)(pl.main_tiles * 2);   // a row per 80-pixel half of a ring tile
   if (!pl.tail) return (int)pl.main_tiles;
   return (int)(pl.main_tiles + (d.M - pl.main_tiles * TileBig::BPX + TileSmall::BPX - 1) / TileSmall::BPX);
 }
@@ -1963,6 +2048,7 @@ static bool fill_dev(const segk_conv_args* a, ConvDev& d) {
   d.M = (long long)a->N * d.HW;
   d.Cout = a->Cout; d.nseg = a->nseg;
   d.n_tiles = 0;
+  d.ring_tiles = 0;
   {
     static const char* abl = experiment("SEGK_DMA_ABL");
     d.abl = abl ? atoi(abl) : 0;
