@@ -1501,8 +1501,9 @@ __global__ __launch_bounds__(STAGES == 3 ? 512 : 256, (PX == 128 && STAGES == 1)
 // no barrier outside the K loop, and a workgroup that walks over several tiles loads the first steps of the next tile
 // while its multipliers still store the previous one: the fixed cost of a tile (about a third of a 36-step tile)
 // disappears behind the K loops of its neighbours.
-//   STAGES = 3, MW = 8 multiplying wavefronts (4 x 2, 32 channels x 80 pixels each): 110 KB of LDS, one workgroup
-//   per CU; STAGES = 2, MW = 4 (2 x 2, 64 x 80 each): two workgroups per CU.
+//   STAGES = 3, LW = 4 loading and MW = 8 multiplying wavefronts (4 x 2, 32 channels x 80 pixels each): 110 KB of
+//   LDS, one workgroup per CU - the form the library uses.  Others (experiment builds): STAGES = 2, MW = 4 (2 x 2,
+//   64 x 80 each), two workgroups per CU; STAGES = 4; LW = 8.
 constexpr int RING_PX = 160;
 constexpr int RING_STAGE_B = (128 + RING_PX) * 128;
 
@@ -1520,18 +1521,24 @@ __device__ __forceinline__ unsigned taps_of_pixel(int y, int x, int d, int H, in
   return (y - d >= 0 ? xb : 0u) | (xb << 3) | (y + d < H ? xb << 6 : 0u);
 }
 
-template <typename TO, int STAGES, int MW>
+template <typename TO, int STAGES, int MW, int LW>
 // (second launch bound = wavefronts per SIMD: one workgroup per CU with three stages, two with two)
-__global__ __launch_bounds__(256 + 64 * MW, (STAGES == 3 ? 1 : 2) * (4 + MW) / 4) void conv_fwd_ring_kernel(const ConvDev p) {
+__global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) / 4) void conv_fwd_ring_kernel(const ConvDev p) {
   typedef TileCfg<128, RING_PX, MW / 2, 2> G;
   constexpr int BKB = 128, MI = G::MI, MJ = G::MJ;
-  constexpr int NB = RING_PX / 32;    // pixel pieces per loading wavefront
+  // LW loading wavefronts share the 16 + 20 one-KiB pieces of a step: piece q = i * LW + wave
+  constexpr int NA = 16 / LW;                         // weight pieces per loading wavefront
+  constexpr int NB = (RING_PX / 8 + LW - 1) / LW;     // pixel pieces (the last one only in the first wavefronts
+                                                      // when 20 is not a multiple of LW)
+  // (array bounds stay literal: with bounds that depend on a template parameter the host pass silently drops the
+  // kernel's launch stub, and the library then fails to load with an undefined symbol)
+  constexpr int NA_MAX = 4, NB_MAX = 5;
   constexpr int AHEAD = STAGES - 1;   // steps the loaders run ahead of the multipliers
   extern __shared__ __attribute__((aligned(16))) char smem[];   // STAGES x ([A 128 rows][B 160 rows] x 128 B, swizzled)
 
   const int wave_all = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const bool loader = wave_all < 4;
-  const int wave = loader ? wave_all : wave_all - 4;
+  const bool loader = wave_all < LW;
+  const int wave = loader ? wave_all : wave_all - LW;
   const int lane = threadIdx.x & 63;
   const long long bz = blockIdx.y;
   const int nseg = __builtin_amdgcn_readfirstlane(p.nseg);
@@ -1597,30 +1604,30 @@ __global__ __launch_bounds__(256 + 64 * MW, (STAGES == 3 ? 1 : 2) * (4 + MW) / 4
       const int total = tile_taps(m0, seg_bits);
       // piece q = i*4 + wave covers tile rows q*8 .. q*8+7; lane l -> row q*8 + (l>>3), LDS slot l&7, which holds
       // source chunk (l&7) ^ (row&7)
-      int wrow[4], ry[NB], rx[NB];
-      bool rvalid[NB];
+      int wrow[NA_MAX], ry[NB_MAX], rx[NB_MAX];
+      bool rvalid[NB_MAX];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int co = co0 + (i * 4 + wave) * 8 + lrow;
+      for (int i = 0; i < NA; ++i) {
+        const int co = co0 + (i * LW + wave) * 8 + lrow;
         wrow[i] = (co < p.Cout ? co : p.Cout - 1) - co0;
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        const long long m = m0 + (i * 4 + wave) * 8 + lrow;
-        rvalid[i] = m < p.M;
+        const long long m = m0 + (i * LW + wave) * 8 + lrow;
+        rvalid[i] = m < p.M && (i * LW + wave) * 8 < RING_PX;
         const int rem = pixel_in_image(rvalid[i] ? m : 0, p.HW);
         ry[i] = rem / p.W;
         rx[i] = rem - ry[i] * p.W;
       }
       int sg = -1, ti = 0, kc = 0, nkc = 0, ntap = 0;
-      int aoff[4], boff[NB];
+      int aoff[NA_MAX], boff[NB_MAX];
       int v_tap = 0, v_ta = 0, v_tb = 0;   // lane t: index and operand offsets of the t-th listed tap of the segment
       unsigned long long ok = 0ull;        // bit 9 * i + tap: the tap may read this lane's i-th pixel row
       __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.seg[0].w, 0, 0, 0);
       const char* bseg = nullptr;
       int a_soff = 0;
       const char* b_base = nullptr;
-      int voff[NB];
+      int voff[NB_MAX];
       auto next_seg = [&]() {              // at most SEGK_MAX_SEG times per tile
         unsigned bits = 0u;
         do {
@@ -1635,9 +1642,9 @@ __global__ __launch_bounds__(256 + 64 * MW, (STAGES == 3 ? 1 : 2) * (4 + MW) / 4
         const int R = s.R, d = s.dil + (int)blockIdx.y * p.dil_step;
         nkc = s.ck_b / BKB;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) aoff[i] = wrow[i] * s.w_ld_b + lchunk;
+        for (int i = 0; i < NA; ++i) aoff[i] = wrow[i] * s.w_ld_b + lchunk;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) boff[i] = ((i * 4 + wave) * 8 + lrow) * (int)s.in_ld_b + lchunk;
+        for (int i = 0; i < NB; ++i) boff[i] = ((i * LW + wave) * 8 + lrow) * (int)s.in_ld_b + lchunk;
         arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(s.w + bz * s.w_batch_b + (long long)co0 * s.w_ld_b), 0, 0x7fffffff,
                                                   0x00020000);
         bseg = s.in + bz * s.in_batch_b + m0 * s.in_ld_b;
@@ -1679,30 +1686,44 @@ __global__ __launch_bounds__(256 + 64 * MW, (STAGES == 3 ? 1 : 2) * (4 + MW) / 4
         }
         set_step();
       };
+      const bool last_b = (NB - 1) * LW + wave < RING_PX / 8;   // this wavefront has a pixel piece in the last round
       auto issue = [&]() {
         char* const sa_w = smem + fill * RING_STAGE_B + wave * 1024;
         char* const sb_w = sa_w + 128 * 128;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void_ptr)(sa_w + i * 4096), 16, aoff[i], a_soff, 0, 0);
+        for (int i = 0; i < NA; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void_ptr)(sa_w + i * (LW * 1024)), 16, aoff[i], a_soff, 0, 0);
         const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NB; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(brsrc, (lds_void_ptr)(sb_w + i * 4096), 16, voff[i], 0, 0, 0);
+          if (i + 1 < NB || last_b)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(brsrc, (lds_void_ptr)(sb_w + i * (LW * 1024)), 16, voff[i], 0, 0, 0);
         fill = fill == STAGES - 1 ? 0 : fill + 1;
+      };
+      // s_waitcnt vmcnt(steps * loads per step of this wavefront): the immediate has to be a literal
+      auto wait_behind = [&](int steps) {
+        const int n = steps <= 0 ? 0 : steps * (NA + NB - (last_b ? 0 : 1));
+        if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (n == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else if (n == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (n == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (not reached: LW is 4 or 8, at most two steps behind)
       };
       if (total > 0) {
         next_seg();
         set_step();
         issue();
-        if (AHEAD == 2 && total > 1) {
+        for (int k = 1; k < AHEAD && k < total; ++k) {
           advance();
           issue();
         }
         for (int st = 0; st < total; ++st) {
-          // this wavefront's loads of step st have landed; with three stages those of step st + 1 may be in flight
-          if (AHEAD == 2 && st + 1 < total) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          // this wavefront's loads of step st have landed; those of the AHEAD - 1 steps behind it may be in flight
+          const int behind = total - 1 - st;
+          wait_behind(behind < AHEAD - 1 ? behind : AHEAD - 1);
           bare_barrier();
           if (st + AHEAD < total) {
             advance();
@@ -1729,26 +1750,74 @@ __global__ __launch_bounds__(256 + 64 * MW, (STAGES == 3 ? 1 : 2) * (4 + MW) / 4
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int st = 0; st < total; ++st) {
-      bare_barrier();
-      if (!(p.abl & 2)) {                  // timing experiment: loads and barriers only
+    if (MW == 8) {
+      // Fragment reads run one half step (32 channels) ahead of the MFMAs: while the MFMAs of one half run, the next
+      // half's fragments arrive in the other register buffer.  Once the second half of step k is on its way the
+      // barrier of step k + 1 follows (its loads have landed; the multipliers' reads of step k are complete), so no
+      // fragment read waits in front of an MFMA - the two multiplying wavefronts of a SIMD leave a barrier together
+      // and would otherwise both sit out the LDS latency before either has an MFMA to issue.
+      u32x4 fa[2][MI], fb[2][MJ];          // [buffer][tile]
+      auto read_half = [&](int buf, int ks) {
         const char* a = smem + stage * RING_STAGE_B;
         const char* b = a + 128 * 128;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          u32x4 fb[MJ];
+        for (int j = 0; j < MJ; ++j)
+          fb[buf][j] = *reinterpret_cast<const u32x4*>(b + tile_off<BKB>(wc * (MJ * 16) + j * 16 + frow, ks * 4 + fg));
 #pragma unroll
-          for (int j = 0; j < MJ; ++j)
-            fb[j] = *reinterpret_cast<const u32x4*>(b + tile_off<BKB>(wc * (MJ * 16) + j * 16 + frow, ks * 4 + fg));
+        for (int i = 0; i < MI; ++i)
+          fa[buf][i] = *reinterpret_cast<const u32x4*>(a + tile_off<BKB>(wr * (MI * 16) + i * 16 + frow, ks * 4 + fg));
+        __builtin_amdgcn_sched_barrier(0);   // the reads are issued here, not after the MFMAs that follow
+      };
+      auto mfmas = [&](int buf) {
 #pragma unroll
-          for (int i = 0; i < MI; ++i) {
-            const u32x4 fa = *reinterpret_cast<const u32x4*>(a + tile_off<BKB>(wr * (MI * 16) + i * 16 + frow, ks * 4 + fg));
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < MJ; ++j) Mma<bf16_t>::run(fa, fb[j], acc[i][j]);
+          for (int j = 0; j < MJ; ++j) Mma<bf16_t>::run(fa[buf][i], fb[buf][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      if (total > 0) {
+        bare_barrier();
+        read_half(0, 0);
+        // (the last step is peeled off: were its missing barrier and reads a branch inside the loop, the compiler's
+        // counted waits in front of the MFMAs would have to assume the path without reads and wait for all of them)
+        for (int st = 0; st + 1 < total; ++st) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          read_half(1, 1);
+          stage = stage == STAGES - 1 ? 0 : stage + 1;
+          mfmas(0);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of step st is complete: its stage is free
+          bare_barrier();
+          read_half(0, 0);
+          mfmas(1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        read_half(1, 1);
+        stage = stage == STAGES - 1 ? 0 : stage + 1;
+        mfmas(0);
+        mfmas(1);
+      }
+    } else {
+      for (int st = 0; st < total; ++st) {
+        bare_barrier();
+        if (!(p.abl & 2)) {                // timing experiment: loads and barriers only
+          const char* a = smem + stage * RING_STAGE_B;
+          const char* b = a + 128 * 128;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            u32x4 fb[MJ];
+#pragma unroll
+            for (int j = 0; j < MJ; ++j)
+              fb[j] = *reinterpret_cast<const u32x4*>(b + tile_off<BKB>(wc * (MJ * 16) + j * 16 + frow, ks * 4 + fg));
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+              const u32x4 fa = *reinterpret_cast<const u32x4*>(a + tile_off<BKB>(wr * (MI * 16) + i * 16 + frow, ks * 4 + fg));
+#pragma unroll
+              for (int j = 0; j < MJ; ++j) Mma<bf16_t>::run(fa, fb[j], acc[i][j]);
+            }
           }
         }
+        stage = stage == STAGES - 1 ? 0 : stage + 1;
       }
-      stage = stage == STAGES - 1 ? 0 : stage + 1;
     }
 
     // Epilogue without LDS or barriers (the loaders are already filling the ring for the next tile): a wavefront's
@@ -1827,7 +1896,7 @@ static int cu_count() {
 
 // The grid of a ring launch: every tile its own workgroup while they all fit on the chip at once, otherwise as many
 // workgroups as fit (a multiple of 8: one run of tiles per XCD), each walking over several tiles.
-template <typename TO, int STAGES, int MW>
+template <typename TO, int STAGES, int MW, int LW = 4>
 static int launch_ring(ConvDev& d, hipStream_t st, int batch, long long px_tiles) {
   constexpr int lds = STAGES * RING_STAGE_B;
   d.n_tiles = ceil_div(d.Cout, 128);
@@ -1837,16 +1906,16 @@ static int launch_ring(ConvDev& d, hipStream_t st, int batch, long long px_tiles
     return SEGK_INVALID_ARG;
   }
   d.ring_tiles = (int)tiles;
-  const long long slots = (long long)cu_count() * (STAGES == 3 ? 1 : 2);
+  const long long slots = (long long)cu_count() * (STAGES >= 3 ? 1 : 2);
   long long grid = (tiles + 7) / 8 * 8;
   if (grid * batch > slots) {
     grid = slots / batch / 8 * 8;
     if (grid < 8) grid = 8;
   }
   static LdsConfigured configured;  // per instantiation
-  int rc = set_lds(conv_fwd_ring_kernel<TO, STAGES, MW>, lds, "conv_fwd_ring", configured);
+  int rc = set_lds(conv_fwd_ring_kernel<TO, STAGES, MW, LW>, lds, "conv_fwd_ring", configured);
   if (rc != SEGK_OK) return rc;
-  conv_fwd_ring_kernel<TO, STAGES, MW><<<dim3((unsigned)grid, (unsigned)batch), 256 + 64 * MW, lds, st>>>(d);
+  conv_fwd_ring_kernel<TO, STAGES, MW, LW><<<dim3((unsigned)grid, (unsigned)batch), 64 * (LW + MW), lds, st>>>(d);
   return SEGK_OK;
 }
 
@@ -1963,19 +2032,20 @@ struct TilePlan {
   int ring;              // form of the 128 x 160 ring tile (bf16 operands, 128-byte K rows), 0 = not used
 };
 
-// Which form of the ring tile serves a problem, 0 = none: every convolution with bf16 operands and 128-byte K rows.
-// Launches whose tiles all fit on the chip at once (one workgroup per CU) and batched launches take the three-stage
-// form, larger ones the two-stage form with two workgroups per CU.  Kernel durations (rocprofv3, batch 16) against
-// the one-stage LDS-DMA tiles they replace: ResNet layer-3 3x3 46 -> 28 us, layer-4 3x3 109 -> 86, ASPP 1x1 45 -> 27,
-// one dilated ASPP 3x3 256 -> 157, the three of them in one launch 555 -> 517, decoder 3x3 514 -> 424 and 400 -> 365,
-// their data gradients 540 -> 472 and 395 -> 352, the ASPP data gradient (four segments) 481 -> 404, decoder 1x1
-// onto 48 channels 59 -> 55.
+// Which form of the ring tile serves a problem, 0 = none: every convolution with bf16 operands and 128-byte K rows
+// takes form 1 (three stages, four loading and eight multiplying wavefronts, one persistent workgroup per CU).
+// Kernel durations (rocprofv3, batch 16) against the one-stage LDS-DMA tiles it replaces: ResNet layer-3 3x3 46 ->
+// 28 us, layer-4 3x3 109 -> 86, ASPP 1x1 45 -> 27, one dilated ASPP 3x3 256 -> 147, the three of them in one launch
+// 555 -> 492, decoder 3x3 514 -> 432 and 400 -> 362, their data gradients 540 -> 478 and 395 -> 355, the ASPP data
+// gradient (four segments, fp32 output) 481 -> 392, decoder 1x1 onto 48 channels 59 -> 55.
+// Experiment builds keep three other forms for comparison (SEGK_CONV_RING=2: two stages, four multipliers of 64 x 80,
+// two workgroups per CU - level on the large launches, 40 % slower on launches of one workgroup per CU; 3: four
+// stages - level; 4: eight loading wavefronts - level: the K loop is not bound by the loaders' instruction issue).
 static int ring_form(const ConvDev& d, bool wide, bool bf16, int batch) {
   if (!wide || !bf16) return 0;
   static const char* e = experiment("SEGK_CONV_RING");
   if (e) return e[0] >= '1' && e[0] <= '4' ? e[0] - '0' : 0;
-  const long long blocks = ((d.M + RING_PX - 1) / RING_PX) * ceil_div(d.Cout, 128) * batch;
-  return blocks <= cu_count() || batch > 1 ? 1 : 2;
+  return 1;
 }
 
 static TilePlan plan_tiles(const ConvDev& d, bool wide, int batch, bool bf16) {
@@ -2126,14 +2196,16 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
 #endif
   if (plan.ring) {
     const int f = plan.ring;
-#define SEGK_RING(S, W) (a->out_dtype == SEGK_BF16 ? launch_ring<bf16_t, S, W>(d, st, batch, plan.main_tiles) \
-                                                   : launch_ring<float, S, W>(d, st, batch, plan.main_tiles))
+    (void)f;
+#define SEGK_RING(S, W, L) (a->out_dtype == SEGK_BF16 ? launch_ring<bf16_t, S, W, L>(d, st, batch, plan.main_tiles) \
+                                                      : launch_ring<float, S, W, L>(d, st, batch, plan.main_tiles))
 #ifdef SEGK_EXPERIMENTS
-    if (f == 3) rc = SEGK_RING(3, 4);
-    else if (f == 4) rc = SEGK_RING(2, 8);
+    if (f == 2) rc = SEGK_RING(2, 4, 4);
+    else if (f == 3) rc = SEGK_RING(4, 8, 4);
+    else if (f == 4) rc = SEGK_RING(3, 8, 8);
     else
 #endif
-    rc = f == 2 ? SEGK_RING(2, 4) : SEGK_RING(3, 8);
+    rc = SEGK_RING(3, 8, 4);
 #undef SEGK_RING
     if (rc != SEGK_OK) return rc;
     SEGK_CHECK_LAUNCH("conv_fwd");
