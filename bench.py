@@ -442,7 +442,7 @@ def main():
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                "traffic": None,
-                               "kernel": "conv_fwd_dma_kernel / conv_fwd_kernel (implicit-GEMM forward + data "
+                               "kernel": "conv_fwd_ring_kernel (bf16) / conv_fwd_dma_kernel / conv_fwd_kernel (implicit-GEMM forward + data "
                                "gradient, all %d segk_conv_fwd calls of the head in the timed steps, each bracketed by two HIP events "
                                "on the launch stream; a call is one launch or a main + tail pair)" % dom["launches"],
                                "avg_launch_ms": dom["avg_ms"], "share_of_step": dom["ms"] / (1000.0 * elapsed)}
@@ -451,7 +451,7 @@ def main():
             ach = wg["flops"] / (wg["ms"] * 1e-3) / 1e12
             out["roofline_wgrad"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                      "avg_launch_ms": wg["avg_ms"],
-                                     "kernel": "conv_wgrad_kernel / conv_wgrad_dma_kernel + wgrad_finish_kernel (%d "
+                                     "kernel": "conv_wgrad_ring_kernel (bf16, 256 output channels) / conv_wgrad_kernel / conv_wgrad_dma_kernel + wgrad_finish_kernel (%d "
                                                "weight gradients of the head: the split-slab launch and the fixed-order "
                                                "slab sum inside one bracket)" % wg["launches"],
                                      "share_of_step": wg["ms"] / (1000.0 * elapsed)}
@@ -507,7 +507,7 @@ def main():
             line.update(conv_rooflines(main_res, args.dtype, args.steps, elapsed))
             if "roofline" in line:
                 calls = main_res["conv"]["conv_fwd_kernel"]["launches"] / float(args.steps)
-                line["roofline"]["traffic"] = measured_traffic(args, ("conv_fwd_dma_kernel", "conv_fwd_kernel"), calls)
+                line["roofline"]["traffic"] = measured_traffic(args, ("conv_fwd_ring_kernel", "conv_fwd_dma_kernel", "conv_fwd_kernel"), calls)
                 line["roofline"]["traffic_unit"] = ("HBM bytes per segk_conv_fwd call (rocprofv3 FETCH_SIZE x2 + "
                                                     "WRITE_SIZE, profiles/pmc_traffic.json: counter passes with the feeder on MIOpen, "
                                                     "so that only the head's launches are counted)")

@@ -127,7 +127,8 @@ typedef struct {
   int splits;      /* >= 1: the pixel range is cut into `splits` parts summed later in fixed order */
   float* slabs;    /* [splits][R*R][Cin][Cout] fp32 partial weight gradients */
   int tile;        /* 0: the library chooses the workgroup tile; 128 / 256: that square tile (256 needs Cout % 256 == 0
-                      and Cin >= 256).  Callers that size `splits` for a given tile pass it here. */
+                      and Cin >= 256); 384: the 256(co) x 128(ci) ring tile (bf16 only; what 0 selects for bf16 when
+                      Cout % 256 == 0).  Callers that size `splits` for a given tile pass it here. */
 } segk_wgrad_args;
 
 /* Weight gradient of nn.Conv2d (autograd of modeling/aspp.py:18, modeling/decoder.py:172,178). */

@@ -1164,9 +1164,19 @@ static int set_lds(K kernel, int bytes, const char* name, LdsConfigured& done) {
   return SEGK_OK;
 }
 
+static int launch_wgrad_ring(WgradDev& d, int batch, hipStream_t st, const char* name);
+
 // Launch the weight-gradient kernel; the 256 x 256 tile is used when the output channels fill it exactly.
+// tile = 384: the 256(co) x 128(ci) ring tile (bf16).
 template <typename T>
 static int launch_wgrad(WgradDev& d, int batch, hipStream_t st, const char* name, int tile = 0) {
+  if (tile == 384 && sizeof(T) != 2) {
+    set_error("%s: the ring tile is bf16 only", name);
+    return SEGK_UNSUPPORTED_SHAPE;
+  }
+  // bf16 onto a multiple of 256 output channels: the ring tile unless the caller names another
+  if (tile == 384 || (tile == 0 && sizeof(T) == 2 && d.Cout % 256 == 0 && !experiment("SEGK_WGRAD_TILE")))
+    return launch_wgrad_ring(d, batch, st, name);
   static const char* force = experiment("SEGK_WGRAD_TILE");  // experiments: "small" (register-staged 128 tile) / "big" / "dma"
   // The 256 x 256 tile when the output channels fill it exactly and the last input-channel tile is more than half
   // full (320 input channels would run a second tile that is a quarter full); otherwise the 128 x 128 tile, for
@@ -1919,6 +1929,225 @@ static int launch_ring(ConvDev& d, hipStream_t st, int batch, long long px_tiles
   return SEGK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient on the ring (bf16): one workgroup owns 256(co) x 128(ci) of one tap over one part of the pixel
+// range and walks over it in chunks of 64 pixels.  A stage holds three LDS images of [64 px][128 channels]
+// (dout channels 0-127, dout channels 128-255, input), the same images and transposing fragment reads as
+// conv_wgrad_dma_kernel; three stages, 144 KB, one workgroup per CU.  Wavefronts 0-3 load (12 one-KiB pieces each
+// per chunk, two chunks ahead, counted vmcnt waits), wavefronts 4-11 multiply (64 x 64 each, fragment reads half a
+// chunk ahead of the MFMAs), one bare barrier per chunk.  Chunks in which the tap reaches no pixel (large
+// dilations on small maps) cost nothing: every wavefront finds them by the same wavefront-wide vote (lane l looks
+// at pixel l of the chunk), so they take no stage and no barrier.
+// ------------------------------------------------------------------------------------------------
+constexpr int WRING_STAGES = 3;
+constexpr int WRING_SUB_B = 64 * 256;             // one [64 px][128 channels] image
+constexpr int WRING_STAGE_B = 3 * WRING_SUB_B;
+
+__global__ __launch_bounds__(768, 3) void conv_wgrad_ring_kernel(const WgradDev p) {
+  typedef bf16_t T;
+  constexpr int BP = 64, MI = 4, MJ = 4, STAGES = WRING_STAGES, AHEAD = STAGES - 1;
+  constexpr int LPW = 12;                           // loads per loading wavefront and chunk
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int wave_all = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool loader = wave_all < 4;
+  const int wave = loader ? wave_all : wave_all - 4;
+  const int lane = threadIdx.x & 63;
+  int b;
+  {
+    const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u, xcd = blockIdx.x & 7u;
+    b = (int)(xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3));
+  }
+  const int cot = b % p.co_tiles; b /= p.co_tiles;
+  const int cit = b % p.ci_tiles; b /= p.ci_tiles;
+  const int taps = p.R * p.R;
+  const int tap = b % taps;
+  const int sp = b / taps;
+  const int co0 = cot * 256, ci0 = cit * 128;
+  const int dy = (tap / p.R - (p.R >> 1)) * p.dil, dx = (tap % p.R - (p.R >> 1)) * p.dil;
+  const long long pbeg = (long long)sp * p.per_split;
+  long long pend = pbeg + p.per_split;
+  if (pend > p.M) pend = p.M;
+  const int nchunks = pbeg < pend ? (int)((pend - pbeg + BP - 1) / BP) : 0;
+  const long long bz = blockIdx.y;
+
+  // lane l follows pixel l of the current chunk: which pixels of the chunk the tap reaches, as a 64-bit vote
+  long long qm = pbeg + lane;
+  int qy, qx;
+  {
+    const int rem = pixel_in_image(qm < p.M ? qm : 0, p.HW);
+    qy = rem / p.W;
+    qx = rem - qy * p.W;
+  }
+  const int step_y = BP / p.W, step_x = BP - step_y * p.W;
+  auto chunk_vote = [&]() -> unsigned long long {
+    const bool ok = qm < pend && (unsigned)(qy + dy) < (unsigned)p.H && (unsigned)(qx + dx) < (unsigned)p.W;
+    const unsigned long long vote = __builtin_amdgcn_ballot_w64(ok);
+    qm += BP;
+    qx += step_x;
+    qy += step_y;
+    if (qx >= p.W) {
+      qx -= p.W;
+      ++qy;
+    }
+    while (qy >= p.H) qy -= p.H;   // next image (several at once only for images smaller than a chunk)
+    return vote;
+  };
+
+  if (loader) {
+    // piece q = i*4 + wave (i = 0..3) covers image rows (pixels) q*4 .. q*4+3; lane l -> row q*4 + (l>>4), LDS slot
+    // l&15 of that row, which holds the source chunk the granule swizzle of wg_chunk_off<bf16_t> assigns to it (the
+    // swizzle key of these rows does not depend on i)
+    const int lr4 = lane >> 4, slot = lane & 15;
+    const int fkey = lr4 | (((wave >> 1) & 1) << 2);
+    const int csrc = ((((slot >> 1) ^ fkey) & 7) << 1) | (slot & 1);
+    const bool dcol0 = co0 + csrc * 8 < p.Cout, dcol1 = co0 + 128 + csrc * 8 < p.Cout, xcol = ci0 + csrc * 8 < p.Cin;
+    int doff[4], xoff[4], lrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      lrow[i] = (i * 4 + wave) * 4 + lr4;
+      doff[i] = lrow[i] * (int)p.dout_ld_b + csrc * 16;
+      xoff[i] = lrow[i] * (int)p.in_ld_b + csrc * 16;
+    }
+    const char* dbase = p.dout + bz * p.dout_batch_b + (size_t)co0 * 2 + pbeg * p.dout_ld_b;
+    const char* xbase = p.in + bz * p.in_batch_b + (size_t)ci0 * 2 + (pbeg + (long long)dy * p.W + dx) * p.in_ld_b;
+    const long long dstep = (long long)BP * p.dout_ld_b, xstep = (long long)BP * p.in_ld_b;
+    int fill = 0, issued = 0, handed = 0;
+    auto wait_behind = [&](int steps) {   // the immediate has to be a literal
+      if (steps <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      static_assert(LPW == 12 && AHEAD == 2, "counted waits are written for 12 loads per chunk, two chunks ahead");
+    };
+    for (int ck = 0; ck < nchunks; ++ck) {
+      const unsigned long long vote = chunk_vote();
+      if (vote != 0ull) {
+        if (issued >= AHEAD) {
+          // hand over the oldest chunk in flight: its loads have landed (the next one's may still fly); behind the
+          // barrier the multipliers have also left the chunk before it, whose stage is filled next
+          wait_behind(AHEAD - 1);
+          bare_barrier();
+          ++handed;
+        }
+        const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dbase, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, 0x7fffffff, 0x00020000);
+        char* const sw = smem + fill * WRING_STAGE_B + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          // rows the tap may not read get an offset beyond the resource's range: the load writes zeros, touches no
+          // memory
+          const bool ok = (vote >> lrow[i]) & 1ull;
+          const int v0 = ok && dcol0 ? doff[i] : (int)0x80000000;
+          const int v1 = ok && dcol1 ? doff[i] + 256 : (int)0x80000000;
+          const int vx = ok && xcol ? xoff[i] : (int)0x80000000;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(drsrc, (lds_void_ptr)(sw + i * 4096), 16, v0, 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(drsrc, (lds_void_ptr)(sw + WRING_SUB_B + i * 4096), 16, v1, 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void_ptr)(sw + 2 * WRING_SUB_B + i * 4096), 16, vx, 0, 0, 0);
+        }
+        fill = fill == STAGES - 1 ? 0 : fill + 1;
+        ++issued;
+      }
+      dbase += dstep;
+      xbase += xstep;
+    }
+    while (handed < issued) {
+      wait_behind(issued - 1 - handed < AHEAD - 1 ? issued - 1 - handed : AHEAD - 1);
+      bare_barrier();
+      ++handed;
+    }
+    return;
+  }
+
+  // multipliers: the number of chunks that take a stage
+  int total = 0;
+  for (int ck = 0; ck < nchunks; ++ck) total += chunk_vote() != 0ull ? 1 : 0;
+  total = __builtin_amdgcn_readfirstlane(total);
+
+  const int wr = wave >> 1, wc = wave & 1;   // co block of 64 (0..3), ci block of 64
+  const bool wave_live = ci0 + wc * 64 < p.Cin && co0 + wr * 64 < p.Cout;
+  f32x4 acc[MI][MJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (!wave_live) {
+    for (int st = 0; st < total; ++st) bare_barrier();
+  } else if (total > 0) {
+    int stage = 0;
+    u32x4 fa[2][MI], fb[2][MJ];          // [buffer][tile]
+    auto read_half = [&](int buf, int ks) {
+      const char* sd = smem + stage * WRING_STAGE_B + (wr >> 1) * WRING_SUB_B;
+      const char* sx = smem + stage * WRING_STAGE_B + 2 * WRING_SUB_B;
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) fb[buf][j] = WgFrag<T>::read(sx, ks, wc * 64 + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[buf][i] = WgFrag<T>::read(sd, ks, (wr & 1) * 64 + i * 16, lane);
+      __builtin_amdgcn_sched_barrier(0);   // the reads are issued here, not after the MFMAs that follow
+    };
+    auto mfmas = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) WgFrag<T>::mma(fa[buf][i], fb[buf][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    bare_barrier();
+    read_half(0, 0);
+    // (the last chunk is peeled off: were its missing barrier and reads a branch inside the loop, the compiler's
+    // counted waits in front of the MFMAs would have to assume the path without reads and wait for all of them)
+    for (int st = 0; st + 1 < total; ++st) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      read_half(1, 1);
+      stage = stage == STAGES - 1 ? 0 : stage + 1;
+      mfmas(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of chunk st is complete: its stage is free
+      bare_barrier();
+      read_half(0, 0);
+      mfmas(1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    read_half(1, 1);
+    mfmas(0);
+    mfmas(1);
+  }
+
+  // acc[i][j][r] = dw[co = co0 + wr*64 + i*16 + (lane>>4)*4 + r][ci = ci0 + wc*64 + j*16 + (lane&15)]
+  const int fq = lane >> 4, fr = lane & 15;
+  float* slab = p.slabs + (((size_t)bz * p.splits + sp) * taps + tap) * p.Cin * p.Cout;
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) {
+    const int ci = ci0 + wc * 64 + j * 16 + fr;
+    if (ci >= p.Cin) continue;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int co = co0 + wr * 64 + i * 16 + fq * 4;
+      if (co >= p.Cout) continue;
+      *reinterpret_cast<f32x4*>(slab + (size_t)ci * p.Cout + co) = acc[i][j];
+    }
+  }
+}
+
+static int launch_wgrad_ring(WgradDev& d, int batch, hipStream_t st, const char* name) {
+  d.co_tiles = ceil_div(d.Cout, 256);
+  d.ci_tiles = ceil_div(d.Cin, 128);
+  const long long nb = (long long)d.co_tiles * d.ci_tiles * d.R * d.R * d.splits;
+  if (nb >= 2147483647LL) {
+    set_error("%s: too many tiles", name);
+    return SEGK_INVALID_ARG;
+  }
+  // per-lane row offsets are 32-bit: 64 rows of the operands have to stay below 2 GB
+  if (d.dout_ld_b * 64 >= 0x7fffffffLL || d.in_ld_b * 64 >= 0x7fffffffLL) {
+    set_error("%s: row stride too large for the ring tile", name);
+    return SEGK_UNSUPPORTED_SHAPE;
+  }
+  constexpr int lds = WRING_STAGES * WRING_STAGE_B;
+  static LdsConfigured configured;
+  int rc = set_lds(conv_wgrad_ring_kernel, lds, name, configured);
+  if (rc != SEGK_OK) return rc;
+  conv_wgrad_ring_kernel<<<dim3((unsigned)nb, (unsigned)batch), 768, lds, st>>>(d);
+  return SEGK_OK;
+}
+
 // px_tiles < 0: every pixel tile from d.m_begin to the end
 template <typename TO, int PX = 128>
 static int launch_dma(ConvDev& d, hipStream_t st, int batch = 1, long long px_tiles = -1) {
@@ -2287,7 +2516,7 @@ extern "C" int segk_conv_wgrad(const segk_wgrad_args* a, segk_stream_t stream) {
   d.slabs = a->slabs;
   d.in_batch_b = 0; d.dout_batch_b = 0;
   hipStream_t st = (hipStream_t)stream;
-  SEGK_REQUIRE(a->tile == 0 || a->tile == 128 || a->tile == 256, "wgrad: tile=%d (0, 128 or 256)", a->tile);
+  SEGK_REQUIRE(a->tile == 0 || a->tile == 128 || a->tile == 256 || a->tile == 384, "wgrad: tile=%d (0, 128, 256 or 384)", a->tile);
   int rc = a->dtype == SEGK_BF16 ? launch_wgrad<bf16_t>(d, 1, st, "conv_wgrad", a->tile)
                                  : launch_wgrad<float>(d, 1, st, "conv_wgrad", a->tile);
   if (rc != SEGK_OK) return rc;

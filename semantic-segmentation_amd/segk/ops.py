@@ -266,8 +266,26 @@ def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=Fals
     return stats
 
 
-def wgrad_plan(M, Cin, Cout, R, dtype):
-    """-> (tile, splits) of a weight gradient: parts of the pixel range so that the launch fills the chip.  The
+def _ring_parts(chunks, Cin, Cout, R, cus=256):
+    """Parts of the pixel range for the ring tile (256 x 128 of one tap per workgroup, one workgroup per CU).  A
+    cost model in microseconds fitted to kernel durations on MI355X: workgroups run in rounds of one per CU, a
+    64-pixel chunk takes 0.9 us, a workgroup has 8 us of fixed cost (prologue, 128 KB slab store), and every part
+    adds a whole fp32 copy of the gradient that the fixed-order sum reads back (0.3 us per MB)."""
+    tiles = (Cout // 256) * ((Cin + 127) // 128) * R * R
+    slab_mb = R * R * Cin * Cout * 4 / 1e6
+    best, best_t = 1, None
+    for sp in range(1, max(1, min(SPLIT_CAP, chunks // 8)) + 1):
+        rounds = (tiles * sp + cus - 1) // cus
+        t = rounds * (0.9 * ((chunks + sp - 1) // sp) + 8.0) + 3.0 + sp * slab_mb * 0.3
+        if best_t is None or t < best_t:
+            best, best_t = sp, t
+    return best
+
+
+def wgrad_plan(M, Cin, Cout, R, dtype, ring=True):
+    """-> (tile, splits) of a weight gradient: parts of the pixel range so that the launch fills the chip.  bf16
+    gradients onto a multiple of 256 output channels take the ring tile (tile code 384, parts from _ring_parts);
+    ring=False gives the plan of the older tiles for everything (comparisons).  The
     256 x 256-tile kernel (Cout a multiple of 256, Cin at least 256 with a last tile more than half full) runs one
     workgroup per CU, the 128 x 128 one two (fp32) or three (bf16, LDS-DMA).  Every part writes a whole fp32 copy of
     the gradient, so with few pixels per part (the 33 x 33 maps of the feeder's layers 3 and 4) the slabs and the
@@ -275,6 +293,8 @@ def wgrad_plan(M, Cin, Cout, R, dtype):
     part) with only as many parts as keep the slabs within SLAB_BUDGET, but at least one workgroup per CU."""
     bp = 64 if dtype == torch.bfloat16 else 32
     chunks = max(1, (M + bp - 1) // bp)
+    if ring and dtype == torch.bfloat16 and Cout % 256 == 0:
+        return 384, _ring_parts(chunks, Cin, Cout, R)
     big = Cin >= 256 and Cout % 256 == 0 and (Cin % 256 == 0 or Cin % 256 > 128)
 
     # a gradient of at most 256 K elements (a 1 MB slab) may be cut into SPLIT_CAP_SMALL parts: its slabs stay

@@ -208,6 +208,34 @@ def test_conv_wgrad_many_parts_small_gradient(ops, dtype, splits):
     assert got16.dtype == torch.bfloat16 and torch.equal(got16.float(), gw.to(torch.bfloat16).float())
 
 
+# N, H, W, Cin, Cout, R, dil, parts: the ring tile (256 x 128 of one tap per workgroup, 64-pixel chunks, chunks the tap
+# does not reach are skipped).  160 / 32 input channels: a last ci tile that is a quarter full (one multiplying
+# wavefront column idle); 512 output channels: two co tiles; dilation 12 on a 17 x 15 map: most chunks of the outer
+# taps are skipped, rows beyond the image in the others; 5 x 5 images: several images per chunk; 7 parts of 2 x 11 x 9
+# pixels: parts 4 to 6 are empty and must still write zero slabs; 1 part over 1200 pixels: 19 chunks, the last partial.
+RING_WGRAD_CASES = [(2, 17, 15, 160, 256, 3, 12, 2), (1, 23, 19, 32, 512, 3, 1, 3), (9, 5, 5, 128, 256, 3, 2, 1),
+                    (2, 11, 9, 64, 256, 1, 1, 7), (3, 20, 20, 256, 256, 3, 18, 1), (1, 33, 33, 96, 256, 3, 6, 4)]
+
+
+@pytest.mark.parametrize("case", RING_WGRAD_CASES)
+def test_conv_wgrad_ring_exact_integers(ops, case):
+    N, H, W, Cin, Cout, R, dil, parts = case
+    x = T(gen.integers(9, "rw_x%s" % (case,), (N, Cin, H, W), -3, 4).astype(np.float32))
+    w = torch.zeros((Cout, Cin, R, R), device=DEV, requires_grad=True)
+    y = F.conv2d(x, w, padding=dil * (R // 2), dilation=dil)
+    gy = T(gen.integers(9, "rw_g%s" % (case,), tuple(y.shape), -2, 3).astype(np.float32))
+    (gw,) = torch.autograd.grad(y, w, gy)
+    _, xfull = to_pm(x, torch.bfloat16)
+    _, gfull = to_pm(gy, torch.bfloat16)
+    got = ops.conv_wgrad(xfull, gfull, N, H, W, R, dil, Cout, Cin, splits=parts, tile=384)
+    assert torch.equal(got, gw)
+    # the library's own choice for these shapes is the same tile; the planned part count
+    assert ops.wgrad_plan(N * H * W, Cin, Cout, R, torch.bfloat16)[0] == 384
+    assert torch.equal(ops.conv_wgrad(xfull, gfull, N, H, W, R, dil, Cout, Cin), gw)
+    # and the older tile agrees
+    assert torch.equal(ops.conv_wgrad(xfull, gfull, N, H, W, R, dil, Cout, Cin, splits=parts, tile=128), gw)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
 def test_conv_wgrad_random_padded_input(ops, dtype, tol):
     """Decoder shape in miniature: 304 real input channels inside a 320-wide buffer."""
