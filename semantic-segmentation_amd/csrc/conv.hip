@@ -1760,7 +1760,7 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (MW == 8) {
+    if (MW == 8 || STAGES == 3) {
       // Fragment reads run one half step (32 channels) ahead of the MFMAs: while the MFMAs of one half run, the next
       // half's fragments arrive in the other register buffer.  Once the second half of step k is on its way the
       // barrier of step k + 1 follows (its loads have landed; the multipliers' reads of step k are complete), so no
@@ -1943,9 +1943,10 @@ constexpr int WRING_STAGES = 3;
 constexpr int WRING_SUB_B = 64 * 256;             // one [64 px][128 channels] image
 constexpr int WRING_STAGE_B = 3 * WRING_SUB_B;
 
-__global__ __launch_bounds__(768, 3) void conv_wgrad_ring_kernel(const WgradDev p) {
+template <int MW>
+__global__ __launch_bounds__(64 * (4 + MW), (4 + MW) / 4) void conv_wgrad_ring_kernel(const WgradDev p) {
   typedef bf16_t T;
-  constexpr int BP = 64, MI = 4, MJ = 4, STAGES = WRING_STAGES, AHEAD = STAGES - 1;
+  constexpr int BP = 64, MI = MW == 8 ? 4 : 8, MJ = 4, STAGES = WRING_STAGES, AHEAD = STAGES - 1;
   constexpr int LPW = 12;                           // loads per loading wavefront and chunk
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -2062,8 +2063,8 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_ring_kernel(const WgradDev 
   for (int ck = 0; ck < nchunks; ++ck) total += chunk_vote() != 0ull ? 1 : 0;
   total = __builtin_amdgcn_readfirstlane(total);
 
-  const int wr = wave >> 1, wc = wave & 1;   // co block of 64 (0..3), ci block of 64
-  const bool wave_live = ci0 + wc * 64 < p.Cin && co0 + wr * 64 < p.Cout;
+  const int wr = wave >> 1, wc = wave & 1;   // co block of MI * 16 channels, ci block of 64
+  const bool wave_live = ci0 + wc * 64 < p.Cin && co0 + wr * (MI * 16) < p.Cout;
   f32x4 acc[MI][MJ];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -2076,12 +2077,12 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_ring_kernel(const WgradDev 
     int stage = 0;
     u32x4 fa[2][MI], fb[2][MJ];          // [buffer][tile]
     auto read_half = [&](int buf, int ks) {
-      const char* sd = smem + stage * WRING_STAGE_B + (wr >> 1) * WRING_SUB_B;
+      const char* sd = smem + stage * WRING_STAGE_B + (MW == 8 ? wr >> 1 : wr) * WRING_SUB_B;
       const char* sx = smem + stage * WRING_STAGE_B + 2 * WRING_SUB_B;
 #pragma unroll
       for (int j = 0; j < MJ; ++j) fb[buf][j] = WgFrag<T>::read(sx, ks, wc * 64 + j * 16, lane);
 #pragma unroll
-      for (int i = 0; i < MI; ++i) fa[buf][i] = WgFrag<T>::read(sd, ks, (wr & 1) * 64 + i * 16, lane);
+      for (int i = 0; i < MI; ++i) fa[buf][i] = WgFrag<T>::read(sd, ks, (MW == 8 ? (wr & 1) * 64 : 0) + i * 16, lane);
       __builtin_amdgcn_sched_barrier(0);   // the reads are issued here, not after the MFMAs that follow
     };
     auto mfmas = [&](int buf) {
@@ -2111,7 +2112,7 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_ring_kernel(const WgradDev 
     mfmas(1);
   }
 
-  // acc[i][j][r] = dw[co = co0 + wr*64 + i*16 + (lane>>4)*4 + r][ci = ci0 + wc*64 + j*16 + (lane&15)]
+  // acc[i][j][r] = dw[co = co0 + wr*MI*16 + i*16 + (lane>>4)*4 + r][ci = ci0 + wc*64 + j*16 + (lane&15)]
   const int fq = lane >> 4, fr = lane & 15;
   float* slab = p.slabs + (((size_t)bz * p.splits + sp) * taps + tap) * p.Cin * p.Cout;
 #pragma unroll
@@ -2120,7 +2121,7 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_ring_kernel(const WgradDev 
     if (ci >= p.Cin) continue;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      const int co = co0 + wr * 64 + i * 16 + fq * 4;
+      const int co = co0 + wr * (MI * 16) + i * 16 + fq * 4;
       if (co >= p.Cout) continue;
       *reinterpret_cast<f32x4*>(slab + (size_t)ci * p.Cout + co) = acc[i][j];
     }
@@ -2141,10 +2142,20 @@ static int launch_wgrad_ring(WgradDev& d, int batch, hipStream_t st, const char*
     return SEGK_UNSUPPORTED_SHAPE;
   }
   constexpr int lds = WRING_STAGES * WRING_STAGE_B;
+#ifdef SEGK_EXPERIMENTS
+  static const char* e = experiment("SEGK_WGRAD_RING");   // 4: four multiplying wavefronts of 128 x 64
+  if (e && e[0] == '4') {
+    static LdsConfigured configured4;
+    int rc4 = set_lds(conv_wgrad_ring_kernel<4>, lds, name, configured4);
+    if (rc4 != SEGK_OK) return rc4;
+    conv_wgrad_ring_kernel<4><<<dim3((unsigned)nb, (unsigned)batch), 512, lds, st>>>(d);
+    return SEGK_OK;
+  }
+#endif
   static LdsConfigured configured;
-  int rc = set_lds(conv_wgrad_ring_kernel, lds, name, configured);
+  int rc = set_lds(conv_wgrad_ring_kernel<8>, lds, name, configured);
   if (rc != SEGK_OK) return rc;
-  conv_wgrad_ring_kernel<<<dim3((unsigned)nb, (unsigned)batch), 768, lds, st>>>(d);
+  conv_wgrad_ring_kernel<8><<<dim3((unsigned)nb, (unsigned)batch), 768, lds, st>>>(d);
   return SEGK_OK;
 }
 
@@ -2273,7 +2284,7 @@ struct TilePlan {
 static int ring_form(const ConvDev& d, bool wide, bool bf16, int batch) {
   if (!wide || !bf16) return 0;
   static const char* e = experiment("SEGK_CONV_RING");
-  if (e) return e[0] >= '1' && e[0] <= '4' ? e[0] - '0' : 0;
+  if (e) return e[0] >= '1' && e[0] <= '5' ? e[0] - '0' : 0;
   return 1;
 }
 
@@ -2432,6 +2443,7 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
     if (f == 2) rc = SEGK_RING(2, 4, 4);
     else if (f == 3) rc = SEGK_RING(4, 8, 4);
     else if (f == 4) rc = SEGK_RING(3, 8, 8);
+    else if (f == 5) rc = SEGK_RING(3, 4, 4);
     else
 #endif
     rc = SEGK_RING(3, 8, 4);

@@ -681,8 +681,9 @@ class SyncBNFunction(torch.autograd.Function):
 
 # ------------------------------------------------- feeder conv + BN + ReLU ----
 class ConvBNReLUFunction(torch.autograd.Function):
-    """relu(bn(conv3x3(x))) of a feeder bottleneck block (newmodeling/backbone/resnet101_2.py:19-21 and
-    Bottleneck.forward, conv2 -> bn2 -> relu; stride 1, padding = dilation) as one unit on the implicit-GEMM
+    """relu(bn(conv(x))) of a feeder bottleneck block (newmodeling/backbone/resnet101_2.py:19-21 and
+    Bottleneck.forward, conv2 -> bn2 -> relu: 3x3, stride 1, padding = dilation; conv1 -> bn1 -> relu: 1x1) as one
+    unit on the implicit-GEMM
     kernels: the convolution's epilogue emits the batch-norm statistics, one pass applies BN + ReLU; backward is the
     BN reduce / apply pair, the weight-gradient GEMM and the data-gradient convolution.  Operands take the
     activation's dtype (bf16 under autocast); the convolution output is kept in that dtype as well, like the
@@ -723,6 +724,69 @@ class ConvBNReLUFunction(torch.autograd.Function):
                 dxp = dgrad([(dy, rec.weight, rec.R, rec.dil)], rec.geom, rec.Cin, grad_dtype_for(x))
                 dx = grad_like(x, dxp, N, H, W)
         return dx, dw, dgamma, dbeta, None, None
+
+
+class ConvBNAddReLUFunction(torch.autograd.Function):
+    """relu(bn(conv1x1(x)) + residual): the tail of a feeder bottleneck block (newmodeling/backbone/resnet101_2.py
+    Bottleneck.forward, conv3 -> bn3 -> += residual -> relu) as one unit: statistics from the convolution's epilogue,
+    one pass applies BN, adds the residual, applies the ReLU and stores its pattern as one bit per element; backward
+    is the BN reduce / apply pair (which also emits the residual's gradient), the weight-gradient GEMM and the
+    data-gradient convolution.  Channels_last operands of one dtype."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, residual, conv, bn):
+        N, Cin, H, W = x.shape
+        R, dil = conv.kernel_size[0], conv.dilation[0]
+        cd = torch.bfloat16 if (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()) else torch.float32
+        xv = _padded_input(to_pm(x, cd))
+        rv = pm_view_of(residual)
+        Cout = weight.shape[0]
+        M = N * H * W
+        if rv is None or rv.dtype != cd or tuple(residual.shape) != (N, Cout, H, W):
+            raise ValueError("the fused residual form needs a channels_last residual of the compute dtype")
+        spec = _BNSpec(bn)
+        raw = torch.empty((M, Cout), dtype=cd, device=x.device)
+        w_op = weight.detach()
+        if w_op.dtype != cd or not ops.weight_usable_in_place(w_op, R, Cout):
+            w_op = ops.pack_weight(w_op, cd)
+        with ops.scoped("@feeder"):
+            stats = ops.conv_fwd([(xv, w_op, R, dil)], N, H, W, Cout, raw, want_stats=spec.training, true_ck=[Cin])
+        if spec.training:
+            coef = _train_coeffs(stats, float(M), spec, gamma, beta)
+        else:
+            coef = ops.bn_coeffs_eval(spec.running_mean, spec.running_var, gamma, beta, spec.eps)
+        y = torch.empty((N, Cout, H, W), dtype=cd, device=x.device, memory_format=torch.channels_last)
+        yv = pm_view_of(y)
+        bits = ops.relu_bits_like(yv) if (_pm_aligned8(raw) and _pm_aligned8(rv)) else None
+        ops.bn_apply(raw, yv, coef, PM, True, res=rv, relu_bits=bits)
+        if CAPTURE is not None:
+            CAPTURE.append((y, None))
+        ctx.saved = (x, xv, raw, coef, bits if bits is not None else yv, weight, (N, H, W), R, dil, spec.training,
+                     spec.sync)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, xv, raw, coef, act, weight, geom, R, dil, training, sync = ctx.saved
+        N, H, W = geom
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        gv = to_pm(g, raw.dtype)
+        partials, cnt = ops.bn_bwd_stat_partials(gv, raw, coef, PM, True, act=act)
+        local, dgb = ops.bn_reduce(partials, cnt, want_f32=True)
+        dbeta, dgamma = dgb[0], dgb[1]
+        gs = _global_sums(local, sync and training)
+        dy = torch.empty_like(raw)
+        dres = torch.empty((N, Cout, H, W), dtype=raw.dtype, device=g.device, memory_format=torch.channels_last)
+        ops.bn_bwd_apply(gv, raw, dy, coef, gs, PM, True, eval_mode=not training, act=act, dres=pm_view_of(dres))
+        with ops.scoped("@feeder"):
+            dw = None
+            if ctx.needs_input_grad[1]:
+                dw = weight_grad(weight, xv, dy, N, H, W, R, dil, Cout, Cin, like=weight)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dxp = dgrad([(dy, weight, R, dil)], geom, Cin, grad_dtype_for(x))
+                dx = grad_like(x, dxp, N, H, W)
+        return dx, dw, dgamma, dbeta, (dres if ctx.needs_input_grad[4] else None), None, None
 
 
 # ------------------------------------------------------------ plain conv ----

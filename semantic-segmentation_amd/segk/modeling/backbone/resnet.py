@@ -48,17 +48,29 @@ class Bottleneck(nn.Module):
         self.dilation = dilation
 
     def forward(self, x):
-        y = _bn_relu(self.bn1, self.relu, self.conv1(x))
-        # batch-norm classes that can run the 3x3 convolution, their own statistics and the ReLU as one unit do so
+        # batch-norm classes that can run a convolution, their own statistics and the ReLU as one unit do so
+        unit = getattr(self.bn1, "forward_conv_relu", None)
+        if unit is not None and self.bn1.can_fuse_conv(self.conv1, x):
+            y = unit(self.conv1, x)
+        else:
+            y = _bn_relu(self.bn1, self.relu, self.conv1(x))
         unit = getattr(self.bn2, "forward_conv_relu", None)
         if unit is not None and self.bn2.can_fuse_conv(self.conv2, y):
             y = unit(self.conv2, y)
         else:
             y = _bn_relu(self.bn2, self.relu2, self.conv2(y))
-        y = self.conv3(y)
-        # the projection runs after the main path: autograd then sums the gradients that
-        # reach x in the same order as the reference does, which keeps training bit-identical
-        res = x if self.downsample is None else self.downsample(x)
+        unit = getattr(self.bn3, "forward_conv_add_relu", None)
+        if unit is not None:
+            # (x receives two gradients, from this path and from conv1: their sum does not depend on the order)
+            res = x if self.downsample is None else self.downsample(x)
+            if self.bn3.can_fuse_conv_residual(self.conv3, y, res):
+                return unit(self.conv3, y, res)
+            y = self.conv3(y)
+        else:
+            y = self.conv3(y)
+            # the projection runs after the main path: autograd then sums the gradients that
+            # reach x in the same order as the reference does, which keeps training bit-identical
+            res = x if self.downsample is None else self.downsample(x)
         fused = getattr(self.bn3, "forward_add_relu", None)
         if fused is not None and self.bn3.can_fuse_residual(y, res):
             return fused(y, res)

@@ -95,6 +95,87 @@ def test_unit_bf16_channels_last_weight_gradient_layout():
         assert rel_err(g.float().cpu().numpy(), ref[k].numpy()) < 2e-2, k
 
 
+def test_unit_1x1_bf16_channels_last():
+    """conv1 -> bn1 -> relu of a layer-3 bottleneck (1x1, 1024 -> 256) as the same unit; narrower 1x1 convolutions
+    stay on the PyTorch path."""
+    from segk.modeling.sync_batchnorm import SynchronizedBatchNorm2d
+    dev, Cin, Cout, n, h, w = "cuda", 1024, 256, 3, 9, 11
+    x = torch.from_numpy(gen.relu_normal(SEED, "f1/x", (n, Cin, h, w)))
+    wt = torch.from_numpy(gen.normal(SEED, "f1/w", (Cout, Cin, 1, 1), std=(2.0 / Cin) ** 0.5))
+    gamma = torch.from_numpy(gen.uniform(SEED, "f1/g", (Cout,), 0.5, 1.5))
+    beta = torch.from_numpy(gen.normal(SEED, "f1/b", (Cout,), std=0.3))
+    gy = torch.from_numpy(gen.normal(SEED, "f1/gy", (n, Cout, h, w)))
+    conv = nn.Conv2d(Cin, Cout, 1, bias=False).to(dev).to(memory_format=torch.channels_last)
+    bn = SynchronizedBatchNorm2d(Cout).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(wt)
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    conv.weight.data = conv.weight.data.to(torch.bfloat16)
+    xd = x.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert bn.can_fuse_conv(conv, xd)
+    assert not SynchronizedBatchNorm2d(128).to(dev).can_fuse_conv(nn.Conv2d(512, 128, 1, bias=False).to(dev), xd[:, :512])
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        y = bn.forward_conv_relu(conv, xd)
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(gy.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+    gw = conv.weight.grad
+    assert gw.dtype == torch.bfloat16 and gw.shape == conv.weight.shape
+    xr = x.bfloat16().float().requires_grad_(True)
+    wr = wt.bfloat16().float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z = F.batch_norm(F.conv2d(xr, wr), torch.zeros(Cout), torch.ones(Cout), gr, br, True, 0.1, 1e-5)
+    (z * (y.detach().float().cpu() > 0).float()).backward(gy.bfloat16().float())
+    assert rel_err(y.detach().float().cpu().numpy(), torch.relu(z).detach().numpy()) < 2e-2
+    for k, g, r in (("dx", xd.grad, xr.grad), ("dw", gw, wr.grad), ("dgamma", bn.weight.grad, gr.grad),
+                    ("dbeta", bn.bias.grad, br.grad)):
+        assert rel_err(g.float().cpu().numpy(), r.numpy()) < 2e-2, k
+
+
+def test_unit_1x1_residual_bf16_channels_last():
+    """conv3 -> bn3 -> += residual -> relu of a layer-3 bottleneck (1x1, 256 -> 1024) as one unit, gradient of the
+    residual included; 128 -> 512 stays on the PyTorch path."""
+    from segk.modeling.sync_batchnorm import SynchronizedBatchNorm2d
+    dev, Cin, Cout, n, h, w = "cuda", 256, 1024, 3, 9, 11
+    x = torch.from_numpy(gen.relu_normal(SEED, "f3/x", (n, Cin, h, w)))
+    res = torch.from_numpy(gen.relu_normal(SEED, "f3/r", (n, Cout, h, w)))
+    wt = torch.from_numpy(gen.normal(SEED, "f3/w", (Cout, Cin, 1, 1), std=(2.0 / Cin) ** 0.5))
+    gamma = torch.from_numpy(gen.uniform(SEED, "f3/g", (Cout,), 0.5, 1.5))
+    beta = torch.from_numpy(gen.normal(SEED, "f3/b", (Cout,), std=0.3))
+    gy = torch.from_numpy(gen.normal(SEED, "f3/gy", (n, Cout, h, w)))
+    conv = nn.Conv2d(Cin, Cout, 1, bias=False).to(dev).to(memory_format=torch.channels_last)
+    bn = SynchronizedBatchNorm2d(Cout).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(wt)
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    conv.weight.data = conv.weight.data.to(torch.bfloat16)
+    cl = lambda t: t.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)  # noqa: E731
+    xd, rd = cl(x), cl(res)
+    assert bn.can_fuse_conv_residual(conv, xd, rd)
+    assert not bn.can_fuse_conv_residual(conv, xd, rd.detach().float())
+    small = nn.Conv2d(128, 512, 1, bias=False).to(dev)
+    assert not SynchronizedBatchNorm2d(512).to(dev).can_fuse_conv_residual(small, xd[:, :128], rd[:, :512])
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        y = bn.forward_conv_add_relu(conv, xd, rd)
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(gy.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+    xr = x.bfloat16().float().requires_grad_(True)
+    rr = res.bfloat16().float().requires_grad_(True)
+    wr = wt.bfloat16().float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(Cout), torch.ones(Cout)
+    z = F.batch_norm(F.conv2d(xr, wr), rm, rv, gr, br, True, 0.1, 1e-5) + rr
+    (z * (y.detach().float().cpu() > 0).float()).backward(gy.bfloat16().float())
+    assert rel_err(y.detach().float().cpu().numpy(), torch.relu(z).detach().numpy()) < 2e-2
+    assert rel_err(bn.running_mean.cpu().numpy(), rm.numpy()) < 1e-2
+    assert rel_err(bn.running_var.cpu().numpy(), rv.numpy()) < 1e-2
+    assert conv.weight.grad.dtype == torch.bfloat16 and rd.grad.stride() == rd.stride()
+    for k, g, r in (("dx", xd.grad, xr.grad), ("dres", rd.grad, rr.grad), ("dw", conv.weight.grad, wr.grad),
+                    ("dgamma", bn.weight.grad, gr.grad), ("dbeta", bn.bias.grad, br.grad)):
+        assert rel_err(g.float().cpu().numpy(), r.numpy()) < 2e-2, k
+
+
 def test_pack_weight_layouts_agree():
     """segk_pack_weight_strided: fp32 OIHW, bf16 OIHW and bf16 channels_last sources give the same operand."""
     from segk import ops
