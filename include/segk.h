@@ -71,6 +71,23 @@ int segk_pack_weight(const float* w_oihw, void* dst, int dst_dtype, int Cout, in
 int segk_pack_weight_strided(const void* w, int w_dtype, long long s_co, long long s_ci, long long s_tap, void* dst,
                              int dst_dtype, int Cout, int Cin, int R, int transpose, segk_stream_t stream);
 
+/* Many weights in one launch (every convolution of the feeder bottlenecks, newmodeling/backbone/resnet101_2.py:31-51,
+ * and of the head re-packs its weight once per optimizer step, train.py:143: one launch instead of ~100 small ones).
+ * `items` is a table of n rows in DEVICE memory; first_block is the running sum of segk_pack_weight_blocks() over
+ * the rows before, total_blocks the sum over all rows.  Each row is packed exactly as segk_pack_weight_strided would. */
+typedef struct segk_pack_item {
+  const void* w;     /* the weight, as segk_pack_weight_strided */
+  void* dst;         /* the packed operand */
+  long long s_co, s_ci, s_tap;
+  int w_dtype, dst_dtype;
+  int Cout, Cin, R, transpose;
+  int first_block;
+  int reserved;
+} segk_pack_item;
+/* workgroups one row needs (host-side arithmetic, no launch); negative status on a bad shape */
+int segk_pack_weight_blocks(int Cout, int Cin, int R, long long s_tap, int transpose);
+int segk_pack_weights(const segk_pack_item* items, int n, int total_blocks, segk_stream_t stream);
+
 typedef struct {
   const void* in;  /* [M][in_ld] activations, args.dtype */
   const void* w;   /* packed weights [R*R][rows = Cout][Ck], args.dtype */

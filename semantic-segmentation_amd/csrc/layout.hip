@@ -69,12 +69,11 @@ __global__ __launch_bounds__(256) void pm_to_nchw_kernel(const TS* __restrict__ 
 // source's own order and writes runs along k.  TPB = all taps for a tap-fastest source (runs of 32*taps elements
 // per output channel), 1 for a channel-fastest source (blockIdx.z = tap; runs of 32 elements).
 template <typename TS, typename TD, int TPB, int PCO>
-__global__ __launch_bounds__(256) void pack_weight_kernel(const TS* __restrict__ w, long long s_co, long long s_ci,
-                                                           long long s_tap, TD* __restrict__ dst, int Cout, int Cin,
-                                                           int taps, int rows, int Ck, int transpose) {
-  __shared__ float tile[TPB][PCO][33];
-  const int co0 = blockIdx.x * PCO, ci0 = blockIdx.y * 32;
-  const int tap0 = TPB == 1 ? blockIdx.z : 0;
+__device__ __forceinline__ void pack_patch(const TS* __restrict__ w, long long s_co, long long s_ci, long long s_tap,
+                                           TD* __restrict__ dst, int Cout, int Cin, int taps, int rows, int Ck,
+                                           int transpose, int bx, int by, int bz, float (*tile)[PCO][33]) {
+  const int co0 = bx * PCO, ci0 = by * 32;
+  const int tap0 = TPB == 1 ? bz : 0;
   constexpr int PATCH = PCO * 32 * TPB;
   for (int i = threadIdx.x; i < PATCH; i += 256) {
     int co_l, ci_l, tap;
@@ -108,6 +107,68 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const TS* __restrict__
         Elem<TD>::store(dst + ((size_t)(taps - 1 - tap0 - tap) * rows + row) * Ck + k, tile[tap][k_l][r_l]);
     }
   }
+}
+
+template <typename TS, typename TD, int TPB, int PCO>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const TS* __restrict__ w, long long s_co, long long s_ci,
+                                                           long long s_tap, TD* __restrict__ dst, int Cout, int Cin,
+                                                           int taps, int rows, int Ck, int transpose) {
+  __shared__ float tile[TPB][PCO][33];
+  pack_patch<TS, TD, TPB, PCO>(w, s_co, s_ci, s_tap, dst, Cout, Cin, taps, rows, Ck, transpose, blockIdx.x, blockIdx.y,
+                               blockIdx.z, tile);
+}
+
+// workgroup grid of one weight's pack: nine taps of a 16 x 32 patch per workgroup for a tap-fastest 3x3 source, else
+// one tap of a 32 x 32 patch
+__host__ __device__ inline void pack_grid(int Cout, int Cin, int taps, long long s_tap, int transpose, int& gx, int& gy,
+                                          int& gz, bool& all_taps) {
+  const int kdim = transpose ? Cout : Cin;
+  const int Ck = (kdim + 31) / 32 * 32;
+  const int co_ext = transpose ? Ck : Cout, ci_ext = transpose ? Cin : Ck;
+  all_taps = taps == 9 && s_tap == 1;
+  gx = (co_ext + (all_taps ? 15 : 31)) / (all_taps ? 16 : 32);
+  gy = (ci_ext + 31) / 32;
+  gz = all_taps ? 1 : taps;
+}
+
+// Many weights in one launch: workgroup b serves the item whose [first_block, next first_block) range holds b and
+// moves the same patch, by the same code, as the single-weight kernel would.
+__global__ __launch_bounds__(256) void pack_weights_kernel(const segk_pack_item* __restrict__ items, int n) {
+  __shared__ float tile_raw[9 * 16 * 33];
+  const int b = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {              // last item with first_block <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].first_block <= b) lo = mid;
+    else hi = mid - 1;
+  }
+  const segk_pack_item it = items[lo];
+  const int taps = it.R * it.R;
+  int gx, gy, gz;
+  bool all_taps;
+  pack_grid(it.Cout, it.Cin, taps, it.s_tap, it.transpose, gx, gy, gz, all_taps);
+  const int local = b - it.first_block;
+  if (local >= gx * gy * gz) return;   // (a table whose block counts were not made by segk_pack_weight_blocks)
+  const int bx = local % gx, by = (local / gx) % gy, bz = local / (gx * gy);
+  const int rows = it.transpose ? it.Cin : it.Cout;
+  const int Ck = ((it.transpose ? it.Cout : it.Cin) + 31) / 32 * 32;
+#define SEGK_PACK(TS, TD)                                                                                             \
+  do {                                                                                                                \
+    if (all_taps)                                                                                                     \
+      pack_patch<TS, TD, 9, 16>((const TS*)it.w, it.s_co, it.s_ci, it.s_tap, (TD*)it.dst, it.Cout, it.Cin, taps, rows, \
+                                Ck, it.transpose, bx, by, bz, reinterpret_cast<float (*)[16][33]>(tile_raw));          \
+    else                                                                                                              \
+      pack_patch<TS, TD, 1, 32>((const TS*)it.w, it.s_co, it.s_ci, it.s_tap, (TD*)it.dst, it.Cout, it.Cin, taps, rows, \
+                                Ck, it.transpose, bx, by, bz, reinterpret_cast<float (*)[32][33]>(tile_raw));          \
+  } while (0)
+  if (it.w_dtype == SEGK_BF16) {
+    if (it.dst_dtype == SEGK_BF16) SEGK_PACK(bf16_t, bf16_t);
+    else SEGK_PACK(bf16_t, float);
+  } else {
+    if (it.dst_dtype == SEGK_BF16) SEGK_PACK(float, bf16_t);
+    else SEGK_PACK(float, float);
+  }
+#undef SEGK_PACK
 }
 
 // dw[co][ci][tap] = sum_s slabs[s][tap][ci][co]
@@ -229,14 +290,14 @@ template <typename TS, typename TD>
 static void launch_pack(const void* w, long long s_co, long long s_ci, long long s_tap, void* dst, int Cout, int Cin,
                         int taps, int rows, int Ck, int transpose, hipStream_t st) {
   // patches cover co up to Cout (or up to Ck when co is the padded k index) and ci likewise
-  const int co_ext = transpose ? Ck : Cout, ci_ext = transpose ? Cin : Ck;
-  if (taps == 9 && s_tap == 1) {   // OIHW: all nine taps of a 16 x 32 patch per block
-    dim3 grid(ceil_div(co_ext, 16), ceil_div(ci_ext, 32));
+  int gx, gy, gz;
+  bool all_taps;
+  pack_grid(Cout, Cin, taps, s_tap, transpose, gx, gy, gz, all_taps);
+  dim3 grid(gx, gy, gz);
+  if (all_taps)   // OIHW: all nine taps of a 16 x 32 patch per block
     pack_weight_kernel<TS, TD, 9, 16><<<grid, 256, 0, st>>>((const TS*)w, s_co, s_ci, s_tap, (TD*)dst, Cout, Cin, taps, rows, Ck, transpose);
-  } else {                         // channels_last, or a 1x1 kernel: one tap of a 32 x 32 patch per block
-    dim3 grid(ceil_div(co_ext, 32), ceil_div(ci_ext, 32), taps);
+  else            // channels_last, or a 1x1 kernel: one tap of a 32 x 32 patch per block
     pack_weight_kernel<TS, TD, 1, 32><<<grid, 256, 0, st>>>((const TS*)w, s_co, s_ci, s_tap, (TD*)dst, Cout, Cin, taps, rows, Ck, transpose);
-  }
 }
 
 extern "C" int segk_pack_weight_strided(const void* w, int w_dtype, long long s_co, long long s_ci, long long s_tap,
@@ -259,6 +320,24 @@ extern "C" int segk_pack_weight_strided(const void* w, int w_dtype, long long s_
     else launch_pack<float, float>(w, s_co, s_ci, s_tap, dst, Cout, Cin, taps, rows, Ck, transpose, st);
   }
   SEGK_CHECK_LAUNCH("pack_weight");
+  return SEGK_OK;
+}
+
+extern "C" int segk_pack_weight_blocks(int Cout, int Cin, int R, long long s_tap, int transpose) {
+  SEGK_REQUIRE(Cout > 0 && Cin > 0 && (R == 1 || R == 3) && s_tap > 0, "pack_weight_blocks: bad shape Cout=%d Cin=%d R=%d",
+               Cout, Cin, R);
+  int gx, gy, gz;
+  bool all_taps;
+  pack_grid(Cout, Cin, R * R, s_tap, transpose, gx, gy, gz, all_taps);
+  const long long blocks = (long long)gx * gy * gz;
+  SEGK_REQUIRE(blocks < 2147483647LL, "pack_weight_blocks: too many workgroups");
+  return (int)blocks;
+}
+
+extern "C" int segk_pack_weights(const segk_pack_item* items, int n, int total_blocks, segk_stream_t stream) {
+  SEGK_REQUIRE(items && n > 0 && total_blocks > 0, "pack_weights: empty table");
+  pack_weights_kernel<<<dim3((unsigned)total_blocks), 256, 0, (hipStream_t)stream>>>(items, n);
+  SEGK_CHECK_LAUNCH("pack_weights");
   return SEGK_OK;
 }
 

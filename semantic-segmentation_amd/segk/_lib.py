@@ -60,6 +60,8 @@ SIGNATURES = {
     "segk_pm_to_nchw": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "segk_pack_weight": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "segk_pack_weight_strided": [c_void_p, c_int, c_ll, c_ll, c_ll, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "segk_pack_weight_blocks": [c_int, c_int, c_int, c_ll, c_int],
+    "segk_pack_weights": [c_void_p, c_int, c_int, c_void_p],
     "segk_conv_fwd": [ctypes.POINTER(ConvArgs), c_void_p],
     "segk_conv_stat_rows": [ctypes.POINTER(ConvArgs)],
     "segk_conv_wgrad": [ctypes.POINTER(WgradArgs), c_void_p],

@@ -5,11 +5,14 @@ slice of a wider concat buffer is just ``buf[:, a:b]``).  Everything here requir
 tensors; nothing computes on the host.
 """
 import ctypes
+import weakref
 
+import numpy as np
 import torch
 
 from . import _lib
 from ._lib import BF16, F32, NCHW, PM, ConvArgs, GemmArgs, GemmTnArgs, WgradArgs, call
+from ._tables import StagedTable
 
 
 def _dt(t):
@@ -160,23 +163,141 @@ def _weight_strides(w):
     return st[0], st[1], s_tap
 
 
+# ---- packed operands of registered weights, kept across a step --------------------------------------------------
+# A convolution weight is packed once per use (forward operand, transposed operand of the data gradient): some 110
+# launches of ~10 us per training step, each in front of the convolution that waits for it.  Weights registered
+# here (segk.optim.SGD registers its parameters) keep their packed operands: pack_weight returns the kept tensor
+# while the weight's version counter is the one it was packed at, and repack_cached_weights() - called by the
+# optimizer right after it has written the weights through raw pointers, which leaves the counters alone - renews
+# all of them in one launch.  A weight changed by a torch operation has a new version and is packed again on use.
+_PACK_ITEM = np.dtype([("w", "<u8"), ("dst", "<u8"), ("s_co", "<i8"), ("s_ci", "<i8"), ("s_tap", "<i8"),
+                       ("w_dtype", "<i4"), ("dst_dtype", "<i4"), ("Cout", "<i4"), ("Cin", "<i4"), ("R", "<i4"),
+                       ("transpose", "<i4"), ("first_block", "<i4"), ("reserved", "<i4")])
+assert _PACK_ITEM.itemsize == 72
+
+
+class _PackEntry:
+    __slots__ = ("dst", "version", "layout")
+
+
+class _WeightPackCache:
+    def __init__(self):
+        self.params = {}     # data_ptr -> weakref of the registered parameter
+        self.entries = {}    # (data_ptr, packed dtype, transpose) -> _PackEntry
+        self.table = None    # StagedTable of the entries, rebuilt when their set changes
+        self.blocks = 0
+        self.keys = None
+
+    def register(self, params):
+        for p in params:
+            if isinstance(p, torch.Tensor) and p.is_cuda and p.dim() == 4 and p.shape[2] == p.shape[3] \
+                    and p.shape[2] in (1, 3):
+                self.params[p.data_ptr()] = weakref.ref(p)
+
+    def owner(self, w):
+        ref = self.params.get(w.data_ptr())
+        p = ref() if ref is not None else None
+        if p is None or p.data_ptr() != w.data_ptr() or p.shape != w.shape or p.stride() != w.stride() \
+                or p.dtype != w.dtype:
+            return None
+        return p
+
+    def sweep(self):
+        dead = [k for k, ref in self.params.items() if ref() is None or ref().data_ptr() != k]
+        for k in dead:
+            del self.params[k]
+        gone = [k for k in self.entries if k[0] not in self.params]
+        for k in gone:
+            del self.entries[k]
+        return bool(dead or gone)
+
+
+_PACKS = _WeightPackCache()
+
+
+def cache_weight_packs(params):
+    """Keep the packed operands of these convolution weights between uses (see repack_cached_weights)."""
+    _PACKS.register(params)
+
+
+def invalidate_weight_packs():
+    """Forget what the kept operands hold: for code that has changed registered weights in place through `.data`
+    (which moves no version counter)."""
+    for e in _PACKS.entries.values():
+        e.version = -1
+
+
+def repack_cached_weights():
+    """Renew every kept packed operand from its weight in one launch (segk_pack_weights).  For callers that change
+    registered weights without torch noticing (segk.optim.SGD's kernels write through raw pointers)."""
+    c = _PACKS
+    if not c.entries:
+        return
+    capturing = torch.cuda.is_current_stream_capturing()
+    if not capturing and c.sweep():
+        c.keys = None
+        if not c.entries:
+            return
+    keys = tuple(c.entries)
+    if c.keys != keys:
+        rows = np.zeros(len(keys), dtype=_PACK_ITEM)
+        first = 0
+        for i, k in enumerate(keys):
+            e = c.entries[k]
+            p = c.params[k[0]]()
+            Cout, Cin, R, s_co, s_ci, s_tap = e.layout
+            rows[i] = (p.data_ptr(), e.dst.data_ptr(), s_co, s_ci, s_tap, _dt(p), _dt(e.dst), Cout, Cin, R,
+                       1 if k[2] else 0, first, 0)
+            first += call("segk_pack_weight_blocks", Cout, Cin, R, s_tap, 1 if k[2] else 0)
+        c.table = StagedTable(rows, c.entries[keys[0]].dst.device)
+        c.table.upload()
+        c.blocks, c.keys = first, keys
+    t0 = _hbm_start()
+    call("segk_pack_weights", ctypes.c_void_p(c.table.ptr()), len(keys), c.blocks, _stream())
+    if t0 is not None:
+        _hbm_stop("pack_weight", sum(_nbytes(c.params[k[0]](), c.entries[k].dst) for k in keys), t0)
+    for k in keys:
+        c.entries[k].version = c.params[k[0]]()._version
+
+
 def pack_weight(w, dtype, transpose=False, out=None):
     """nn.Conv2d weight [Cout,Cin,R,R] (fp32 or bf16; contiguous or channels_last) -> [taps, rows, Ck] operand
-    (see segk_pack_weight); `out` may be a contiguous slice of a larger buffer of that shape."""
+    (see segk_pack_weight); `out` may be a contiguous slice of a larger buffer of that shape.  Without `out`, a
+    weight registered with cache_weight_packs gets its kept operand (packed again only if the weight's version
+    counter moved)."""
     _dev(w)
     if w.dtype not in (torch.float32, torch.bfloat16):
         raise ValueError("weights are float32 or bfloat16")
     Cout, Cin, R, S = w.shape
     dense = w.is_contiguous() or w.is_contiguous(memory_format=torch.channels_last)
+    entry = None
+    if out is None and dense and _PACKS.params:
+        owner = _PACKS.owner(w)
+        if owner is not None:
+            key = (w.data_ptr(), dtype, bool(transpose))
+            entry = _PACKS.entries.get(key)
+            if entry is not None and entry.version == owner._version:
+                return entry.dst
+            # (no new entry while a graph is recorded: a kept operand must not live in the graph's memory pool)
+            if entry is None and not torch.cuda.is_current_stream_capturing():
+                entry = _PACKS.entries[key] = _PackEntry()
+                entry.dst = None
+            if entry is not None:
+                entry.version = owner._version
     if not dense:
         w = w.contiguous()
     s_co, s_ci, s_tap = _weight_strides(w)
     rows, k = (Cin, Cout) if transpose else (Cout, Cin)
     shape = (R * R, rows, round_up(k, 32))
     if out is None:
-        out = torch.empty(shape, dtype=dtype, device=w.device)
+        if entry is not None and entry.dst is not None:
+            out = entry.dst
+        else:
+            out = torch.empty(shape, dtype=dtype, device=w.device)
     elif tuple(out.shape) != shape or out.dtype != dtype or not out.is_contiguous():
         raise ValueError("pack_weight destination must be a contiguous %s tensor of shape %s" % (dtype, shape))
+    if entry is not None:
+        entry.dst, entry.layout = out, (Cout, Cin, R, s_co, s_ci, s_tap)
     t0 = _hbm_start()
     call("segk_pack_weight_strided", _ptr(w), _dt(w), s_co, s_ci, s_tap, _ptr(out), _dt(out), Cout, Cin, R,
          1 if transpose else 0, _stream())

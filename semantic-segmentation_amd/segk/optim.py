@@ -108,6 +108,9 @@ class SGD(torch.optim.Optimizer):
                     st["master"] = flat_storage(p.data)                    # fp32: updated in place
                 flat_storage(p.data)
                 st["momentum_buffer"] = torch.zeros(p.numel(), dtype=torch.float32, device=p.device)
+        # convolution weights keep their packed operands between uses; step() renews them in one launch
+        from . import ops
+        ops.cache_weight_packs([p for g in self.param_groups for p in g["params"]])
 
     @torch.no_grad()
     def step(self, closure=None, flat_grads=None):
@@ -132,6 +135,9 @@ class SGD(torch.optim.Optimizer):
             else:
                 call("segk_sgd_step", ctypes.c_void_p(grp.staged.ptr()), n, float(hp["lr"]), float(hp["momentum"]),
                      float(hp["weight_decay"]), stream)
+        # the kernels above wrote the weights through raw pointers: torch's version counters did not move
+        from . import ops
+        ops.repack_cached_weights()
         return loss
 
     def sync_hyper(self):
@@ -217,6 +223,8 @@ class SGD(torch.optim.Optimizer):
                     p.data.copy_(master)
         self._groups = None   # rebuild the chunk tables on the next step
         self._groups_src = None
+        from . import ops
+        ops.invalidate_weight_packs()   # p.data.copy_ above moved no version counter
 
     @torch.no_grad()
     def load_full_precision_state_dict(self, model, state_dict, strict=True):
@@ -230,6 +238,8 @@ class SGD(torch.optim.Optimizer):
                 master = self._shaped(self.state[p]["master"], p)
                 master.copy_(state_dict[k].reshape(p.shape))
                 p.data.copy_(master)
+        from . import ops
+        ops.invalidate_weight_packs()
         return result
 
     def full_precision_state_dict(self, model):

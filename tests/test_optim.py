@@ -243,3 +243,46 @@ def test_c_abi_communicator_single_rank():
     with pytest.raises(_lib.SegkError):
         _lib.call("segk_allreduce_f32", ctypes.c_void_p(f.data_ptr()), f.numel(), st)
     assert lib is not None
+
+
+@pytest.mark.gpu
+def test_kept_weight_packs_follow_the_optimizer():
+    """Convolution weights of a segk.optim.SGD keep their packed operands (ops.pack_weight returns the kept tensor
+    while the weight's version counter stands); the optimizer's step, which writes the weights through raw pointers,
+    renews all of them in one launch (segk_pack_weights), bit-identical to packing each weight on its own: fp32 OIHW
+    3x3 and 1x1 (the head), bf16 channels_last 3x3 and 1x1 (the feeder), forward and transposed operands, channel
+    counts that are no multiples of 32."""
+    from segk import ops
+    from segk.optim import SGD
+    dev = "cuda"
+    g = torch.Generator(device="cpu").manual_seed(11)
+    shapes = [(48, 304, 3, 3), (21, 256, 1, 1), (256, 128, 3, 3), (128, 1024, 1, 1), (40, 24, 3, 3)]
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g).to(dev)) for s in shapes]
+    for k in (2, 3):
+        ps[k].data = ps[k].data.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    opt = SGD(ps, lr=0.1, momentum=0.9, weight_decay=1e-4)
+    uses = [(p, dt, tr) for p in ps for dt in ((torch.bfloat16,) if p.dtype == torch.bfloat16 else (torch.float32, torch.bfloat16))
+            for tr in (False, True)]
+    kept = [ops.pack_weight(p.detach(), dt, transpose=tr) for p, dt, tr in uses]
+    for (p, dt, tr), k in zip(uses, kept):
+        assert ops.pack_weight(p.detach(), dt, transpose=tr) is k          # unchanged weight: the kept operand
+        assert torch.equal(k, ops.pack_weight(p.detach().clone(), dt, transpose=tr))
+    for step in range(2):
+        for p in ps:
+            p.grad = torch.randn(p.shape, generator=g).to(dev).to(p.dtype).contiguous(
+                memory_format=torch.channels_last if p.dtype == torch.bfloat16 else torch.contiguous_format)
+        opt.step()
+        for (p, dt, tr), k in zip(uses, kept):
+            got = ops.pack_weight(p.detach(), dt, transpose=tr)
+            assert got is k and got.data_ptr() == k.data_ptr()
+            assert torch.equal(got, ops.pack_weight(p.detach().clone(), dt, transpose=tr)), (tuple(p.shape), dt, tr, step)
+    # a torch operation moves the version counter: packed again on use, into the same tensor
+    with torch.no_grad():
+        ps[0].mul_(0.5)
+    got = ops.pack_weight(ps[0].detach(), torch.bfloat16)
+    assert torch.equal(got, ops.pack_weight(ps[0].detach().clone(), torch.bfloat16))
+    # in-place changes through .data move no counter: the caller has to say so
+    ps[1].data.add_(1.0)
+    ops.invalidate_weight_packs()
+    got = ops.pack_weight(ps[1].detach(), torch.float32, transpose=True)
+    assert torch.equal(got, ops.pack_weight(ps[1].detach().clone(), torch.float32, transpose=True))
