@@ -68,7 +68,9 @@ struct ConvDev {
   int ring_tiles;        // ring tile: pixel tiles x output-channel tiles of the launch (workgroups may walk over several)
   int abl;               // timing experiments of the LDS-DMA tile (experiment builds only; results are garbage), a
                          // bit mask: 1 = every load reads the zero page, 2 = no fragment reads / MFMAs, 4 = no
-                         // per-step address bookkeeping, 8 = no output stores, 16 = no K loop (fixed cost only)
+                         // per-step address bookkeeping, 8 = no output stores, 16 = no K loop (fixed cost only),
+                         // 32 = raised issue priority for the multiplying wavefronts as well, 64 = none for the loading ones
+                         // (both with valid results)
 };
 
 template <typename T>
@@ -1603,6 +1605,9 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
   };
 
   if (loader) {
+    // the loading wavefronts issue ahead of the multiplying ones on their SIMD: a load delayed behind a run of MFMAs
+    // is a late stage for everybody (kernel durations 1-4 % shorter on 19 of 21 shapes; bit 64: default priority)
+    if (!(p.abl & 64)) __builtin_amdgcn_s_setprio(3);
     const int lrow = lane >> 3;
     const int lchunk = ((lane & 7) ^ lrow) << 4;   // piece rows are 8-aligned: row & 7 == lrow
     int fill = 0;                                  // stage of the next step to issue
@@ -1748,6 +1753,7 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
   const int wr = wave >> 1, wc = wave & 1;
   const int frow = lane & 15, fg = lane >> 4;
   int stage = 0;
+  if (p.abl & 32) __builtin_amdgcn_s_setprio(3);     // timing experiment: multiplying wavefronts issue first
   for (unsigned v = blockIdx.x; in_range(v); v += gridDim.x) {
     const unsigned tile = tile_of(v);
     const int co0 = (int)(tile % (unsigned)p.n_tiles) * G::BCO;
