@@ -488,6 +488,24 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_nchw_kernel(
 // ---------------------------------------------------------------------------------------------
 // Block = 16 columns x 16 row phases; each thread sums rows phase, phase+16, ... of its column, then the 16
 // phase sums of a column are added in phase order: a fixed summation order, independent of scheduling.
+// Sum of rows ph, ph + 16, ... of one column, added in that order.  Sixteen loads are issued before the first
+// addition: these launches sit between two kernels that wait for them and are pure latency (a few hundred rows of
+// a few KB), so the number of dependent round trips to memory is what they cost.  (Rows past the end add 0.0.)
+__device__ __forceinline__ double phase_sum(const double* __restrict__ partials, int rows, int n2, int col, int ph) {
+  double s = 0.0;
+  for (int r0 = ph; r0 < rows; r0 += 16 * 16) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int r = r0 + u * 16;
+      v[u] = r < rows ? partials[(size_t)r * n2 + col] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += v[u];
+  }
+  return s;
+}
+
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const double* __restrict__ partials, int rows, int C,
                                                          double count, double* __restrict__ sums,
                                                          float* __restrict__ sums_f32) {
@@ -496,10 +514,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const double* __restrict
   const int ph = threadIdx.x >> 4;
   const int n2 = 2 * C;
   double s = 0.0;
-  if (col < n2) {
-#pragma unroll 4
-    for (int r = ph; r < rows; r += 16) s += partials[(size_t)r * n2 + col];
-  }
+  if (col < n2) s = phase_sum(partials, rows, n2, col, ph);
   red[ph][threadIdx.x & 15] = s;
   __syncthreads();
   if (threadIdx.x < 16) {
@@ -564,9 +579,7 @@ __global__ __launch_bounds__(256) void bn_reduce_coeffs_kernel(const double* __r
   const int n2 = 2 * C;
   double s = 0.0;
   if (ch < C) {
-    const int col = (j >> 3) * C + ch;
-#pragma unroll 4
-    for (int r = ph; r < rows; r += 16) s += partials[(size_t)r * n2 + col];
+    s = phase_sum(partials, rows, n2, (j >> 3) * C + ch, ph);
   }
   red[ph][j] = s;
   __syncthreads();
