@@ -67,7 +67,7 @@ struct ConvDev {
   long long stat_row0;   // statistic partial row of this launch's first pixel tile
   int ring_tiles;        // ring tile: pixel tiles x output-channel tiles of the launch (workgroups may walk over several)
   int abl;               // timing experiments of the LDS-DMA tile (experiment builds only; results are garbage), a
-                         // bit mask: 1 = every load reads the zero page, 2 = no fragment reads / MFMAs, 4 = no
+                         // bit mask: 1 = every load reads the zero page (ring tile: out of range, no memory access), 2 = no fragment reads / MFMAs, 4 = no
                          // per-step address bookkeeping, 8 = no output stores, 16 = no K loop (fixed cost only),
                          // 32 = raised issue priority for the multiplying wavefronts as well, 64 = none for the loading ones
                          // (both with valid results)
@@ -1689,6 +1689,12 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
         // rows the tap may not read get an offset beyond the resource's range: the load writes zeros, touches no memory
 #pragma unroll
         for (int i = 0; i < NB; ++i) voff[i] = ((sh >> (9 * i)) & 1ull) ? boff[i] : (int)0x80000000;
+#ifdef SEGK_EXPERIMENTS
+        if (p.abl & 1) {                   // timing experiment: every load out of range (zeros, no memory access)
+#pragma unroll
+          for (int i = 0; i < NB; ++i) voff[i] = (int)0x80000000;
+        }
+#endif
       };
       auto advance = [&]() {
         if (p.abl & 4) return;             // timing experiment: every step loads the first step's tiles
@@ -1706,8 +1712,14 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
         char* const sa_w = smem + fill * RING_STAGE_B + wave * 1024;
         char* const sb_w = sa_w + 128 * 128;
 #pragma unroll
-        for (int i = 0; i < NA; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void_ptr)(sa_w + i * (LW * 1024)), 16, aoff[i], a_soff, 0, 0);
+        for (int i = 0; i < NA; ++i) {
+#ifdef SEGK_EXPERIMENTS
+          const int av = (p.abl & 1) ? (int)0x80000000 : aoff[i];
+#else
+          const int av = aoff[i];
+#endif
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void_ptr)(sa_w + i * (LW * 1024)), 16, av, a_soff, 0, 0);
+        }
         const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NB; ++i)
@@ -1774,6 +1786,9 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
       // and would otherwise both sit out the LDS latency before either has an MFMA to issue.
       u32x4 fa[2][MI], fb[2][MJ];          // [buffer][tile]
       auto read_half = [&](int buf, int ks) {
+#ifdef SEGK_EXPERIMENTS
+        if (p.abl & 2) return;             // timing experiment: loads and barriers only
+#endif
         const char* a = smem + stage * RING_STAGE_B;
         const char* b = a + 128 * 128;
 #pragma unroll
@@ -1785,6 +1800,9 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
         __builtin_amdgcn_sched_barrier(0);   // the reads are issued here, not after the MFMAs that follow
       };
       auto mfmas = [&](int buf) {
+#ifdef SEGK_EXPERIMENTS
+        if (p.abl & (2 | 128)) return;     // timing experiments: ... and fragment reads without the MFMAs (128)
+#endif
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
