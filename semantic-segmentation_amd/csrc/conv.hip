@@ -1634,99 +1634,8 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
         ry[i] = rem / p.W;
         rx[i] = rem - ry[i] * p.W;
       }
-      int sg = -1, ti = 0, kc = 0, nkc = 0, ntap = 0;
       int aoff[NA_MAX], boff[NB_MAX];
-      int v_tap = 0, v_ta = 0, v_tb = 0;   // lane t: index and operand offsets of the t-th listed tap of the segment
-      unsigned long long ok = 0ull;        // bit 9 * i + tap: the tap may read this lane's i-th pixel row
-      __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.seg[0].w, 0, 0, 0);
-      const char* bseg = nullptr;
-      int a_soff = 0;
-      const char* b_base = nullptr;
-      int voff[NB_MAX];
-      auto next_seg = [&]() {              // at most SEGK_MAX_SEG times per tile
-        unsigned bits = 0u;
-        do {
-          ++sg;
-          // (readfirstlane: the compiler's uniformity analysis loses these values, and a resource descriptor it takes
-          // for divergent costs a readfirstlane loop around every load)
-          bits = __builtin_amdgcn_readfirstlane(sg == 0 ? seg_bits[0] : sg == 1 ? seg_bits[1] : sg == 2 ? seg_bits[2] : seg_bits[3]);
-        } while (bits == 0u);
-        sg = __builtin_amdgcn_readfirstlane(sg);
-        ntap = __popc(bits);
-        const SegDev& s = p.seg[sg];
-        const int R = s.R, d = s.dil + (int)blockIdx.y * p.dil_step;
-        nkc = s.ck_b / BKB;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) aoff[i] = wrow[i] * s.w_ld_b + lchunk;
-#pragma unroll
-        for (int i = 0; i < NB; ++i) boff[i] = ((i * LW + wave) * 8 + lrow) * (int)s.in_ld_b + lchunk;
-        arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(s.w + bz * s.w_batch_b + (long long)co0 * s.w_ld_b), 0, 0x7fffffff,
-                                                  0x00020000);
-        bseg = s.in + bz * s.in_batch_b + m0 * s.in_ld_b;
-        // lane l takes the l-th listed tap
-        int tap = 0, seen = 0;
-        for (int t = 0; t < R * R; ++t) {
-          const bool listed = (bits >> t) & 1u;
-          if (listed && seen == lane) tap = t;
-          seen += listed ? 1 : 0;
-        }
-        const int dy = R == 1 ? 0 : (tap / 3 - 1) * d, dx = R == 1 ? 0 : (tap % 3 - 1) * d;
-        v_tap = tap;
-        v_ta = (int)((long long)tap * s.w_tap_b);
-        v_tb = (int)(((long long)dy * p.W + dx) * s.in_ld_b);
-        ok = 0ull;
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-          const unsigned m9 = !rvalid[i] ? 0u : R == 1 ? 1u : taps_of_pixel(ry[i], rx[i], d, p.H, p.W);
-          ok |= (unsigned long long)m9 << (9 * i);
-        }
-      };
-      auto set_step = [&]() {
-        const int tap = __builtin_amdgcn_readlane(v_tap, ti);
-        a_soff = __builtin_amdgcn_readlane(v_ta, ti) + kc * BKB;
-        b_base = bseg + __builtin_amdgcn_readlane(v_tb, ti) + kc * BKB;
-        const unsigned long long sh = ok >> tap;
-        // rows the tap may not read get an offset beyond the resource's range: the load writes zeros, touches no memory
-#pragma unroll
-        for (int i = 0; i < NB; ++i) voff[i] = ((sh >> (9 * i)) & 1ull) ? boff[i] : (int)0x80000000;
-#ifdef SEGK_EXPERIMENTS
-        if (p.abl & 1) {                   // timing experiment: every load out of range (zeros, no memory access)
-#pragma unroll
-          for (int i = 0; i < NB; ++i) voff[i] = (int)0x80000000;
-        }
-#endif
-      };
-      auto advance = [&]() {
-        if (p.abl & 4) return;             // timing experiment: every step loads the first step's tiles
-        if (++ti >= ntap) {
-          ti = 0;
-          if (++kc >= nkc) {
-            kc = 0;
-            next_seg();
-          }
-        }
-        set_step();
-      };
       const bool last_b = (NB - 1) * LW + wave < RING_PX / 8;   // this wavefront has a pixel piece in the last round
-      auto issue = [&]() {
-        char* const sa_w = smem + fill * RING_STAGE_B + wave * 1024;
-        char* const sb_w = sa_w + 128 * 128;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-#ifdef SEGK_EXPERIMENTS
-          const int av = (p.abl & 1) ? (int)0x80000000 : aoff[i];
-#else
-          const int av = aoff[i];
-#endif
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void_ptr)(sa_w + i * (LW * 1024)), 16, av, a_soff, 0, 0);
-        }
-        const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-          if (i + 1 < NB || last_b)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(brsrc, (lds_void_ptr)(sb_w + i * (LW * 1024)), 16, voff[i], 0, 0, 0);
-        fill = fill == STAGES - 1 ? 0 : fill + 1;
-      };
       // s_waitcnt vmcnt(steps * loads per step of this wavefront): the immediate has to be a literal
       auto wait_behind = [&](int steps) {
         const int n = steps <= 0 ? 0 : steps * (NA + NB - (last_b ? 0 : 1));
@@ -1739,25 +1648,136 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
         else if (n == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (not reached: LW is 4 or 8, at most two steps behind)
       };
-      if (total > 0) {
-        next_seg();
-        set_step();
-        issue();
-        for (int k = 1; k < AHEAD && k < total; ++k) {
-          advance();
-          issue();
-        }
-        for (int st = 0; st < total; ++st) {
-          // this wavefront's loads of step st have landed; those of the AHEAD - 1 steps behind it may be in flight
-          const int behind = total - 1 - st;
-          wait_behind(behind < AHEAD - 1 ? behind : AHEAD - 1);
+#ifdef SEGK_EXPERIMENTS
+      // timing experiment (bit 256): cycles this wavefront spends waiting for its loads, at the barrier and issuing
+      // the loads, and in the whole tile (the rest is bookkeeping); the first workgroup's loading wavefronts leave
+      // them in the statistics buffer (whose contents are then no statistics)
+      long long c_wait = 0, c_bar = 0, c_iss = 0;
+      const bool stamp = (p.abl & 256) != 0;
+      const long long c_begin = stamp ? __builtin_readcyclecounter() : 0;
+#endif
+      // The hand-over protocol of a tile: its first AHEAD steps are issued at once (their stages are free: the
+      // multipliers left them before the last barrier of the tile before); from then on the oldest step in flight
+      // is handed over before the next is issued - this wavefront's loads of it have landed (those of the AHEAD - 1
+      // steps behind it may be in flight), and behind the barrier the multipliers have left the step before it,
+      // whose stage is filled next.
+      int issued = 0, handed = 0;
+      auto hand_over = [&](int behind) {
+#ifdef SEGK_EXPERIMENTS
+        if (stamp) {
+          const long long t0 = __builtin_readcyclecounter();
+          wait_behind(behind);
+          const long long t1 = __builtin_readcyclecounter();
           bare_barrier();
-          if (st + AHEAD < total) {
-            advance();
-            issue();
+          c_wait += t1 - t0;
+          c_bar += __builtin_readcyclecounter() - t1;
+          ++handed;
+          return;
+        }
+#endif
+        wait_behind(behind);
+        bare_barrier();
+        ++handed;
+      };
+      int sg = -1;
+      for (int done = 0; done < total;) {
+        // the next segment with listed taps (at most SEGK_MAX_SEG per tile)
+        unsigned bits = 0u;
+        do {
+          ++sg;
+          // (readfirstlane: the compiler's uniformity analysis loses these values, and a resource descriptor it takes
+          // for divergent costs a readfirstlane loop around every load)
+          bits = __builtin_amdgcn_readfirstlane(sg == 0 ? seg_bits[0] : sg == 1 ? seg_bits[1] : sg == 2 ? seg_bits[2] : seg_bits[3]);
+        } while (bits == 0u);
+        sg = __builtin_amdgcn_readfirstlane(sg);
+        const int ntap = __popc(bits);
+        const SegDev& s = p.seg[sg];
+        const int R = s.R, d = s.dil + (int)blockIdx.y * p.dil_step;
+        const int nkc = s.ck_b / BKB;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) aoff[i] = wrow[i] * s.w_ld_b + lchunk;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) boff[i] = ((i * LW + wave) * 8 + lrow) * (int)s.in_ld_b + lchunk;
+#ifdef SEGK_EXPERIMENTS
+        if (p.abl & 1) {                   // timing experiment: every load out of range (zeros, no memory access)
+#pragma unroll
+          for (int i = 0; i < NA; ++i) aoff[i] = (int)0x80000000;
+        }
+#endif
+        const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(s.w + bz * s.w_batch_b + (long long)co0 * s.w_ld_b), 0, 0x7fffffff, 0x00020000);
+        const char* const bseg = s.in + bz * s.in_batch_b + m0 * s.in_ld_b;
+        // lane l takes the l-th listed tap: its index and its two operand offsets
+        int tap = 0, seen = 0;
+        for (int t = 0; t < R * R; ++t) {
+          const bool listed = (bits >> t) & 1u;
+          if (listed && seen == lane) tap = t;
+          seen += listed ? 1 : 0;
+        }
+        const int dy = R == 1 ? 0 : (tap / 3 - 1) * d, dx = R == 1 ? 0 : (tap % 3 - 1) * d;
+        const int v_tap = tap;
+        const int v_ta = (int)((long long)tap * s.w_tap_b);
+        const int v_tb = (int)(((long long)dy * p.W + dx) * s.in_ld_b);
+        // Everything a step needs is laid out here, once per segment, under a compile-time tap slot t: the offsets of
+        // this lane's pixel pieces (rows the tap may not read get an offset beyond the resource's range: the load
+        // writes zeros and touches no memory).  A step is then two v_readlane with a literal lane, two additions and
+        // the loads; looking the tap up per step (a dependent chain of v_readlane, 64-bit shifts and selects) cost
+        // 450 of the 1040 cycles a loading wavefront needed per step.
+        unsigned m9[NB_MAX];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) m9[i] = !rvalid[i] ? 0u : R == 1 ? 1u : taps_of_pixel(ry[i], rx[i], d, p.H, p.W);
+        int voff[9][NB_MAX];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int tp = __builtin_amdgcn_readlane(v_tap, t);
+#pragma unroll
+          for (int i = 0; i < NB; ++i) voff[t][i] = ((m9[i] >> tp) & 1u) ? boff[i] : (int)0x80000000;
+#ifdef SEGK_EXPERIMENTS
+          if (p.abl & 1) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) voff[t][i] = (int)0x80000000;
+          }
+#endif
+        }
+        for (int kc = 0; kc < nkc; ++kc) {
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            if (t < ntap) {
+              if (issued >= AHEAD) hand_over(AHEAD - 1);
+#ifdef SEGK_EXPERIMENTS
+              const long long i0 = stamp ? __builtin_readcyclecounter() : 0;
+#endif
+              const int a_soff = __builtin_amdgcn_readlane(v_ta, t) + kc * BKB;
+              const char* const b_base = bseg + __builtin_amdgcn_readlane(v_tb, t) + kc * BKB;
+              char* const sa_w = smem + fill * RING_STAGE_B + wave * 1024;
+              char* const sb_w = sa_w + 128 * 128;
+#pragma unroll
+              for (int i = 0; i < NA; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void_ptr)(sa_w + i * (LW * 1024)), 16, aoff[i], a_soff, 0, 0);
+              const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+              for (int i = 0; i < NB; ++i)
+                if (i + 1 < NB || last_b)
+                  __builtin_amdgcn_raw_ptr_buffer_load_lds(brsrc, (lds_void_ptr)(sb_w + i * (LW * 1024)), 16, voff[t][i], 0, 0, 0);
+              fill = fill == STAGES - 1 ? 0 : fill + 1;
+              ++issued;
+#ifdef SEGK_EXPERIMENTS
+              if (stamp) c_iss += __builtin_readcyclecounter() - i0;
+#endif
+            }
           }
         }
+        done += ntap * nkc;
       }
+      while (handed < issued) hand_over(issued - 1 - handed < AHEAD - 1 ? issued - 1 - handed : AHEAD - 1);
+#ifdef SEGK_EXPERIMENTS
+      if (stamp && p.stat && blockIdx.x == 0 && lane == 0 && v == blockIdx.x) {
+        double* o = p.stat + wave * 8;
+        const long long all = __builtin_readcyclecounter() - c_begin;
+        o[0] = (double)c_wait; o[1] = (double)c_bar; o[2] = (double)(all - c_wait - c_bar - c_iss); o[3] = (double)c_iss;
+        o[4] = (double)total;
+      }
+#endif
     }
     return;
   }
@@ -1857,7 +1877,12 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
     // Epilogue without LDS or barriers (the loaders are already filling the ring for the next tile): a wavefront's
     // statistics go to a partial row of its own (two rows per pixel tile, one per 80-pixel half).
     // acc[i][j][r] = out[pixel = wc*MJ*16 + j*16 + (lane&15)][co = wr*MI*16 + i*16 + (lane>>4)*4 + r]
-    if (p.stat) {
+#ifdef SEGK_EXPERIMENTS
+    const bool want_stat = p.stat && !(p.abl & 256);   // (bit 256: the buffer holds the loaders' cycle counts)
+#else
+    const bool want_stat = p.stat != nullptr;
+#endif
+    if (want_stat) {
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         double sv[4], qv[4];
