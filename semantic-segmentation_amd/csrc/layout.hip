@@ -188,15 +188,15 @@ __global__ void wgrad_finish_kernel(const float* __restrict__ slabs, int splits,
     float acc = 0.f;
     if (ci < Cin && co < Cout) {
       const float* p = slabs + ((size_t)tap * Cin + ci) * Cout + co;
-      int s = 0;
-      for (; s + 8 <= splits; s += 8) {   // eight loads in flight, added in slab order
-        float v[8];
+      // sixteen loads in flight, added in slab order (parts past the end add 0.0): one round trip to memory for
+      // up to sixteen parts - the launch is latency, not bandwidth, for the part counts the plans choose
+      for (int s = 0; s < splits; s += 16) {
+        float v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(s + u) * slab];
+        for (int u = 0; u < 16; ++u) v[u] = s + u < splits ? p[(size_t)(s + u) * slab] : 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u];
+        for (int u = 0; u < 16; ++u) acc += v[u];
       }
-      for (; s < splits; ++s) acc += p[(size_t)s * slab];
     }
     tile[ty + i * 8][tx] = acc;
   }
