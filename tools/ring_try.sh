@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/ring_try.sh <forms...>   (GPU box, experiment build): for each form of the ring tile (SEGK_CONV_RING=1..4;
+# usage: tools/ring_try.sh <forms...>   (GPU box, experiment build): for each form of the ring tile (SEGK_CONV_RING=1..5;
 # 0 = the default kernels) the convolution tests, then kernel durations of tools/conv_bench.py
 set -o pipefail
 for r in "$@"; do
