@@ -1992,6 +1992,14 @@ constexpr int WRING_STAGES = 3;
 constexpr int WRING_SUB_B = 64 * 256;             // one [64 px][128 channels] image
 constexpr int WRING_STAGE_B = 3 * WRING_SUB_B;
 
+#ifdef SEGK_EXPERIMENTS
+// timing experiment (SEGK_WGRAD_STAMP=1): cycles of the first workgroup's wavefronts per phase, [wavefront][8]:
+// loaders: vote + bookkeeping, waiting for loads, barrier, issue, chunks that took a stage; multipliers: barrier
+// waits, everything else in the K loop, -, -, chunks
+__device__ long long wring_stamps[12 * 8];
+__device__ int wring_stamp_on;
+#endif
+
 template <int MW>
 __global__ __launch_bounds__(64 * (4 + MW), (4 + MW) / 4) void conv_wgrad_ring_kernel(const WgradDev p) {
   typedef bf16_t T;
@@ -2068,16 +2076,36 @@ __global__ __launch_bounds__(64 * (4 + MW), (4 + MW) / 4) void conv_wgrad_ring_k
       else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       static_assert(LPW == 12 && AHEAD == 2, "counted waits are written for 12 loads per chunk, two chunks ahead");
     };
+#ifdef SEGK_EXPERIMENTS
+    const bool stamp = wring_stamp_on != 0 && blockIdx.x == 0 && blockIdx.y == 0;
+    long long c_wait = 0, c_bar = 0, c_iss = 0;
+    const long long c_begin = __builtin_readcyclecounter();
+#endif
     for (int ck = 0; ck < nchunks; ++ck) {
       const unsigned long long vote = chunk_vote();
       if (vote != 0ull) {
         if (issued >= AHEAD) {
           // hand over the oldest chunk in flight: its loads have landed (the next one's may still fly); behind the
           // barrier the multipliers have also left the chunk before it, whose stage is filled next
+#ifdef SEGK_EXPERIMENTS
+          const long long t0 = stamp ? __builtin_readcyclecounter() : 0;
+#endif
           wait_behind(AHEAD - 1);
+#ifdef SEGK_EXPERIMENTS
+          const long long t1 = stamp ? __builtin_readcyclecounter() : 0;
+#endif
           bare_barrier();
           ++handed;
+#ifdef SEGK_EXPERIMENTS
+          if (stamp) {
+            c_wait += t1 - t0;
+            c_bar += __builtin_readcyclecounter() - t1;
+          }
+#endif
         }
+#ifdef SEGK_EXPERIMENTS
+        const long long i0 = stamp ? __builtin_readcyclecounter() : 0;
+#endif
         const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dbase, 0, 0x7fffffff, 0x00020000);
         const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, 0x7fffffff, 0x00020000);
         char* const sw = smem + fill * WRING_STAGE_B + wave * 1024;
@@ -2095,15 +2123,27 @@ __global__ __launch_bounds__(64 * (4 + MW), (4 + MW) / 4) void conv_wgrad_ring_k
         }
         fill = fill == STAGES - 1 ? 0 : fill + 1;
         ++issued;
+#ifdef SEGK_EXPERIMENTS
+        if (stamp) c_iss += __builtin_readcyclecounter() - i0;
+#endif
       }
       dbase += dstep;
       xbase += xstep;
     }
+#ifdef SEGK_EXPERIMENTS
+    const long long c_loop = __builtin_readcyclecounter() - c_begin;
+#endif
     while (handed < issued) {
       wait_behind(issued - 1 - handed < AHEAD - 1 ? issued - 1 - handed : AHEAD - 1);
       bare_barrier();
       ++handed;
     }
+#ifdef SEGK_EXPERIMENTS
+    if (stamp && lane == 0) {
+      long long* o = wring_stamps + wave_all * 8;
+      o[0] = c_loop - c_wait - c_bar - c_iss; o[1] = c_wait; o[2] = c_bar; o[3] = c_iss; o[4] = issued;
+    }
+#endif
     return;
   }
 
@@ -2141,6 +2181,11 @@ __global__ __launch_bounds__(64 * (4 + MW), (4 + MW) / 4) void conv_wgrad_ring_k
         for (int j = 0; j < MJ; ++j) WgFrag<T>::mma(fa[buf][i], fb[buf][j], acc[i][j]);
       __builtin_amdgcn_sched_barrier(0);
     };
+#ifdef SEGK_EXPERIMENTS
+    const bool stamp = wring_stamp_on != 0 && blockIdx.x == 0 && blockIdx.y == 0;
+    long long c_bar = 0;
+    const long long c_begin = __builtin_readcyclecounter();
+#endif
     bare_barrier();
     read_half(0, 0);
     // (the last chunk is peeled off: were its missing barrier and reads a branch inside the loop, the compiler's
@@ -2151,7 +2196,13 @@ __global__ __launch_bounds__(64 * (4 + MW), (4 + MW) / 4) void conv_wgrad_ring_k
       stage = stage == STAGES - 1 ? 0 : stage + 1;
       mfmas(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of chunk st is complete: its stage is free
+#ifdef SEGK_EXPERIMENTS
+      const long long t0 = stamp ? __builtin_readcyclecounter() : 0;
+#endif
       bare_barrier();
+#ifdef SEGK_EXPERIMENTS
+      if (stamp) c_bar += __builtin_readcyclecounter() - t0;
+#endif
       read_half(0, 0);
       mfmas(1);
     }
@@ -2159,6 +2210,12 @@ __global__ __launch_bounds__(64 * (4 + MW), (4 + MW) / 4) void conv_wgrad_ring_k
     read_half(1, 1);
     mfmas(0);
     mfmas(1);
+#ifdef SEGK_EXPERIMENTS
+    if (stamp && lane == 0) {
+      long long* o = wring_stamps + wave_all * 8;
+      o[0] = c_bar; o[1] = __builtin_readcyclecounter() - c_begin - c_bar; o[4] = total;
+    }
+#endif
   }
 
   // acc[i][j][r] = dw[co = co0 + wr*MI*16 + i*16 + (lane>>4)*4 + r][ci = ci0 + wc*64 + j*16 + (lane&15)]
@@ -2177,7 +2234,25 @@ __global__ __launch_bounds__(64 * (4 + MW), (4 + MW) / 4) void conv_wgrad_ring_k
   }
 }
 
+#ifdef SEGK_EXPERIMENTS
+// (experiment builds only, not part of the interface) out[12][8]: the stamps of the last ring weight-gradient launch
+extern "C" int segk_debug_wring_stamps(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(wring_stamps), sizeof(long long) * 96) == hipSuccess ? 0 : -1;
+}
+#endif
+
 static int launch_wgrad_ring(WgradDev& d, int batch, hipStream_t st, const char* name) {
+#ifdef SEGK_EXPERIMENTS
+  {
+    static const char* e = experiment("SEGK_WGRAD_STAMP");
+    static bool told = false;
+    if (!told) {
+      const int on = e && e[0] == '1' ? 1 : 0;
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(wring_stamp_on), &on, sizeof(int));
+      told = true;
+    }
+  }
+#endif
   d.co_tiles = ceil_div(d.Cout, 256);
   d.ci_tiles = ceil_div(d.Cin, 128);
   const long long nb = (long long)d.co_tiles * d.ci_tiles * d.R * d.R * d.splits;
