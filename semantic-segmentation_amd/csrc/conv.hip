@@ -147,6 +147,68 @@ __device__ __forceinline__ double row16_sum(double v) {
   return v;
 }
 
+// One DPP move of a double: lane i of the result holds v of the lane that CTRL names for it; lanes outside the row /
+// bank masks keep `old`.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ double dpp_mov_f64(double old, double v) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, BANK_MASK, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, BANK_MASK, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Sums NV doubles per lane over the 16 lanes of a DPP row and leaves them spread over those lanes: afterwards
+// v[0 .. NV/16) of lane l hold the row totals of the original indices row16_scatter_base<NV>(l) + k.  Four halving
+// exchanges (partner lane l^1, l^2, l^8, l^4): a lane keeps the half of its values its bit selects and adds the
+// partner's copy of that half, so the exchange of step s moves NV / 2^s values instead of NV - 15 additions per 16
+// values in all, where summing every value with row16_sum takes 64.
+template <int NV>
+__device__ __forceinline__ void row16_reduce_scatter(double (&v)[NV], int lane) {
+  static_assert(NV % 16 == 0, "one or more values per lane must remain");
+  {
+    const bool up = lane & 1;
+    constexpr int H = NV / 2;
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+      const double keep = up ? v[k + H] : v[k], send = up ? v[k] : v[k + H];
+      v[k] = keep + dpp_mov_f64<0xB1>(0.0, send);          // quad_perm [1,0,3,2]
+    }
+  }
+  {
+    const bool up = lane & 2;
+    constexpr int H = NV / 4;
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+      const double keep = up ? v[k + H] : v[k], send = up ? v[k] : v[k + H];
+      v[k] = keep + dpp_mov_f64<0x4E>(0.0, send);          // quad_perm [2,3,0,1]
+    }
+  }
+  {
+    const bool up = lane & 8;
+    constexpr int H = NV / 8;
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+      const double keep = up ? v[k + H] : v[k], send = up ? v[k] : v[k + H];
+      v[k] = keep + dpp_mov_f64<0x128>(0.0, send);         // row_ror:8
+    }
+  }
+  {
+    const bool up = lane & 4;
+    constexpr int H = NV / 16;
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+      const double keep = up ? v[k + H] : v[k], send = up ? v[k] : v[k + H];
+      // partner l^4: lanes 0-3 and 8-11 of a row (banks 0, 2) read four lanes up, the others four lanes down
+      double t = dpp_mov_f64<0x104, 0xf, 0x5>(0.0, send);  // row_shl:4
+      t = dpp_mov_f64<0x114, 0xf, 0xA>(t, send);           // row_shr:4
+      v[k] = keep + t;
+    }
+  }
+}
+template <int NV>
+__device__ __forceinline__ int row16_scatter_base(int lane) {
+  return ((lane & 1) ? NV / 2 : 0) + ((lane & 2) ? NV / 4 : 0) + ((lane & 8) ? NV / 8 : 0) + ((lane & 4) ? NV / 16 : 0);
+}
+
 // Epilogue shared by the forward kernels: optional fp64 batch-norm statistics of the unbiased accumulators, then
 // bias / per-image bias and the store.  acc[i][j][r] = out[pixel = wc*MJ*16 + j*16 + (lane&15)]
 //                                                         [co = wr*MI*16 + i*16 + (lane>>4)*4 + r]
@@ -1517,7 +1579,6 @@ __global__ __launch_bounds__(STAGES == 3 ? 512 : 256, (PX == 128 && STAGES == 1)
 //   LDS, one workgroup per CU - the form the library uses.  Others (experiment builds): STAGES = 2, MW = 4 (2 x 2,
 //   64 x 80 each), two workgroups per CU; STAGES = 4; LW = 8.
 constexpr int RING_PX = 160;
-constexpr int RING_STAGE_B = (128 + RING_PX) * 128;
 
 __device__ __forceinline__ void bare_barrier() {
   asm volatile("" ::: "memory");        // the compiler keeps memory operations on their side of the barrier
@@ -1533,18 +1594,20 @@ __device__ __forceinline__ unsigned taps_of_pixel(int y, int x, int d, int H, in
   return (y - d >= 0 ? xb : 0u) | (xb << 3) | (y + d < H ? xb << 6 : 0u);
 }
 
-template <typename TO, int STAGES, int MW, int LW>
+template <typename TO, int STAGES, int MW, int LW, int BCO = 128>
 // (second launch bound = wavefronts per SIMD: one workgroup per CU with three stages, two with two)
 __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) / 4) void conv_fwd_ring_kernel(const ConvDev p) {
-  typedef TileCfg<128, RING_PX, MW / 2, 2> G;
+  typedef TileCfg<BCO, RING_PX, MW / 2, 2> G;
   constexpr int BKB = 128, MI = G::MI, MJ = G::MJ;
-  // LW loading wavefronts share the 16 + 20 one-KiB pieces of a step: piece q = i * LW + wave
-  constexpr int NA = 16 / LW;                         // weight pieces per loading wavefront
+  constexpr int STAGE_B = (BCO + RING_PX) * 128;      // one stage: the weight tile, then the pixel tile
+  // LW loading wavefronts share the BCO / 8 + 20 one-KiB pieces of a step: piece q = i * LW + wave
+  constexpr int NA = BCO / 8 / LW;                    // weight pieces per loading wavefront
   constexpr int NB = (RING_PX / 8 + LW - 1) / LW;     // pixel pieces (the last one only in the first wavefronts
                                                       // when 20 is not a multiple of LW)
   // (array bounds stay literal: with bounds that depend on a template parameter the host pass silently drops the
   // kernel's launch stub, and the library then fails to load with an undefined symbol)
-  constexpr int NA_MAX = 4, NB_MAX = 5;
+  constexpr int NA_MAX = 8, NB_MAX = 5;
+  static_assert(NA <= NA_MAX && NB <= NB_MAX, "loader piece tables too small");
   constexpr int AHEAD = STAGES - 1;   // steps the loaders run ahead of the multipliers
   extern __shared__ __attribute__((aligned(16))) char smem[];   // STAGES x ([A 128 rows][B 160 rows] x 128 B, swizzled)
 
@@ -1645,6 +1708,8 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
         else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (n == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         else if (n == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (n == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (n == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
         else if (n == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (not reached: LW is 4 or 8, at most two steps behind)
       };
@@ -1749,8 +1814,8 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
 #endif
               const int a_soff = __builtin_amdgcn_readlane(v_ta, t) + kc * BKB;
               const char* const b_base = bseg + __builtin_amdgcn_readlane(v_tb, t) + kc * BKB;
-              char* const sa_w = smem + fill * RING_STAGE_B + wave * 1024;
-              char* const sb_w = sa_w + 128 * 128;
+              char* const sa_w = smem + fill * STAGE_B + wave * 1024;
+              char* const sb_w = sa_w + BCO * 128;
 #pragma unroll
               for (int i = 0; i < NA; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void_ptr)(sa_w + i * (LW * 1024)), 16, aoff[i], a_soff, 0, 0);
@@ -1798,7 +1863,80 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (MW == 8 || STAGES == 3) {
+    if constexpr (MI == 4) {
+      // 256 output channels per tile: a multiplying wavefront owns 64 channels x 80 pixels, 40 MFMAs per step in four
+      // units of ten (one half of the step's 64 contracted channels x one pair of 16-channel blocks).  The fragments
+      // of a unit arrive while the unit before it multiplies: the pixel fragments of a half step in a buffer of
+      // their own (two buffers), the weight fragments of a pair in one of two small ones - 56 registers of fragments
+      // beside 80 accumulators, which keeps three wavefronts per SIMD (one loading, two multiplying) resident.
+      u32x4 fb[2][MJ];   // [half of the step]
+      u32x4 fa[2][2];    // [unit parity][block of the pair]
+      auto read_b = [&](int ks) {
+#ifdef SEGK_EXPERIMENTS
+        if (p.abl & 2) return;             // timing experiment: loads and barriers only
+#endif
+        const char* b = smem + stage * STAGE_B + BCO * 128;
+#pragma unroll
+        for (int j = 0; j < MJ; ++j)
+          fb[ks][j] = *reinterpret_cast<const u32x4*>(b + tile_off<BKB>(wc * (MJ * 16) + j * 16 + frow, ks * 4 + fg));
+      };
+      auto read_a = [&](int buf, int pair, int ks) {
+#ifdef SEGK_EXPERIMENTS
+        if (p.abl & 2) return;
+#endif
+        const char* a = smem + stage * STAGE_B;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          fa[buf][i] = *reinterpret_cast<const u32x4*>(a + tile_off<BKB>(wr * 64 + (pair * 2 + i) * 16 + frow, ks * 4 + fg));
+        __builtin_amdgcn_sched_barrier(0);   // the reads are issued here, not after the MFMAs that follow
+      };
+      auto unit = [&](int buf, int pair, int ks) {
+#ifdef SEGK_EXPERIMENTS
+        if (p.abl & (2 | 128)) return;     // timing experiments: ... and fragment reads without the MFMAs (128)
+#endif
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < MJ; ++j) Mma<bf16_t>::run(fa[buf][i], fb[ks][j], acc[pair * 2 + i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      if (total > 0) {
+        bare_barrier();
+        read_b(0);
+        read_a(0, 0, 0);
+        for (int st = 0; st + 1 < total; ++st) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          read_a(1, 1, 0);
+          unit(0, 0, 0);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          read_b(1);
+          read_a(0, 0, 1);
+          unit(1, 1, 0);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          read_a(1, 1, 1);
+          unit(0, 0, 1);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of step st is complete: its stage is free
+          stage = stage == STAGES - 1 ? 0 : stage + 1;
+          bare_barrier();
+          read_b(0);
+          read_a(0, 0, 0);
+          unit(1, 1, 1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        read_a(1, 1, 0);
+        unit(0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        read_b(1);
+        read_a(0, 0, 1);
+        unit(1, 1, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        read_a(1, 1, 1);
+        unit(0, 0, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stage = stage == STAGES - 1 ? 0 : stage + 1;
+        unit(1, 1, 1);
+      }
+    } else if (MW == 8 || STAGES == 3) {
       // Fragment reads run one half step (32 channels) ahead of the MFMAs: while the MFMAs of one half run, the next
       // half's fragments arrive in the other register buffer.  Once the second half of step k is on its way the
       // barrier of step k + 1 follows (its loads have landed; the multipliers' reads of step k are complete), so no
@@ -1809,8 +1947,8 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
 #ifdef SEGK_EXPERIMENTS
         if (p.abl & 2) return;             // timing experiment: loads and barriers only
 #endif
-        const char* a = smem + stage * RING_STAGE_B;
-        const char* b = a + 128 * 128;
+        const char* a = smem + stage * STAGE_B;
+        const char* b = a + BCO * 128;
 #pragma unroll
         for (int j = 0; j < MJ; ++j)
           fb[buf][j] = *reinterpret_cast<const u32x4*>(b + tile_off<BKB>(wc * (MJ * 16) + j * 16 + frow, ks * 4 + fg));
@@ -1854,8 +1992,8 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
       for (int st = 0; st < total; ++st) {
         bare_barrier();
         if (!(p.abl & 2)) {                // timing experiment: loads and barriers only
-          const char* a = smem + stage * RING_STAGE_B;
-          const char* b = a + 128 * 128;
+          const char* a = smem + stage * STAGE_B;
+          const char* b = a + BCO * 128;
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
             u32x4 fb[MJ];
@@ -1883,42 +2021,82 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
     const bool want_stat = p.stat != nullptr;
 #endif
     if (want_stat) {
+      // per lane: sums over its MJ pixels (fp64: the squares of fp32 accumulators are exact), then over the 16
+      // pixels of the DPP row; two 16-channel blocks at a time (index (i & 1) * 4 + r for the sums, 8 more for the
+      // squares) so that only 16 doubles are live beside the accumulators
+      double* row = p.stat + bz * p.stat_batch + (size_t)((p.stat_row0 + mt) * 2 + wc) * 2 * p.Cout;
+      const int base = row16_scatter_base<16>(lane);
+      const int co_l = co0 + wr * (MI * 16) + ((base & 7) >> 2) * 16 + fg * 4 + (base & 3);
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        double sv[4], qv[4];
+      for (int i0 = 0; i0 < MI; i0 += 2) {
+        double v[16];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          double sum = 0.0, sq = 0.0;
-#pragma unroll
-          for (int j = 0; j < MJ; ++j) {
-            const double t = (double)acc[i][j][r];
-            sum += t;
-            sq = fma(t, t, sq);
-          }
-          sv[r] = row16_sum(sum);
-          qv[r] = row16_sum(sq);
-        }
-        if (frow == 0) {
-          double* row = p.stat + bz * p.stat_batch + (size_t)((p.stat_row0 + mt) * 2 + wc) * 2 * p.Cout;
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int co = co0 + wr * (MI * 16) + i * 16 + fg * 4 + r;
-            if (co < p.Cout) {
-              row[co] = sv[r];
-              row[p.Cout + co] = qv[r];
+            double sum = 0.0, sq = 0.0;
+#pragma unroll
+            for (int j = 0; j < MJ; ++j) {
+              const double t = (double)acc[i0 + ii][j][r];
+              sum += t;
+              sq = fma(t, t, sq);
             }
+            v[ii * 4 + r] = sum;
+            v[8 + ii * 4 + r] = sq;
           }
-        }
+        row16_reduce_scatter<16>(v, lane);
+        const int co = co_l + i0 * 16;
+        if (co < p.Cout) row[(size_t)(base >> 3) * p.Cout + co] = v[0];
       }
     }
     if (p.abl & 8) continue;               // timing experiment: no output stores
     const int cpad = (p.Cout + 3) & ~3;
+    char* const obase = p.out + bz * p.out_batch_b;
+    // every channel of the tile exists and nothing is added to the accumulators (the same in every lane): no
+    // per-element tests; bf16 outputs leave as 16 bytes per lane - a lane swaps its four channels of an odd / even
+    // 16-channel block with the lane 16 further on, which holds the four channels beside them
+    const bool plain = __builtin_amdgcn_readfirstlane((co0 + BCO <= p.Cout && !p.bias && !p.img_bias) ? 1 : 0) != 0;
+    if (plain) {
+      if constexpr (sizeof(TO) == 2) {
+        const bool wide16 = __builtin_amdgcn_readfirstlane(((((uintptr_t)obase) & 15) == 0 && (p.out_ld & 7) == 0) ? 1 : 0) != 0;
+        if (wide16) {
+          const int cbase = co0 + wr * (MI * 16) + ((fg & 1) ? 16 + (fg - 1) * 4 : fg * 4);
+#pragma unroll
+          for (int j = 0; j < MJ; ++j) {
+            const long long m = m0 + wc * (MJ * 16) + j * 16 + frow;
+            char* orow = obase + ((size_t)m * p.out_ld + cbase) * 2;
+#pragma unroll
+            for (int i = 0; i < MI; i += 2) {
+              unsigned a0 = pack_bf16x2(acc[i][j][0], acc[i][j][1]), a1 = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+              unsigned b0 = pack_bf16x2(acc[i + 1][j][0], acc[i + 1][j][1]), b1 = pack_bf16x2(acc[i + 1][j][2], acc[i + 1][j][3]);
+              const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+              const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+              const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+              if (m < p.M) *reinterpret_cast<u32x4*>(orow + i * 32) = o;
+            }
+          }
+          continue;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) {
+        const long long m = m0 + wc * (MJ * 16) + j * 16 + frow;
+        if (m >= p.M) continue;
+        char* orow = obase + ((size_t)m * p.out_ld + co0 + wr * (MI * 16) + fg * 4) * sizeof(TO);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          store_out4<TO>(orow + i * 16 * sizeof(TO), o);
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int j = 0; j < MJ; ++j) {
       const long long m = m0 + wc * (MJ * 16) + j * 16 + frow;
       if (m >= p.M) continue;
       const float* ib = p.img_bias ? p.img_bias + (m / p.HW) * p.Cout : nullptr;
-      char* orow = p.out + bz * p.out_batch_b + (size_t)m * p.out_ld * sizeof(TO);
+      char* orow = obase + (size_t)m * p.out_ld * sizeof(TO);
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int c = co0 + wr * (MI * 16) + i * 16 + fg * 4;
@@ -1955,10 +2133,10 @@ static int cu_count() {
 
 // The grid of a ring launch: every tile its own workgroup while they all fit on the chip at once, otherwise as many
 // workgroups as fit (a multiple of 8: one run of tiles per XCD), each walking over several tiles.
-template <typename TO, int STAGES, int MW, int LW = 4>
+template <typename TO, int STAGES, int MW, int LW = 4, int BCO = 128>
 static int launch_ring(ConvDev& d, hipStream_t st, int batch, long long px_tiles) {
-  constexpr int lds = STAGES * RING_STAGE_B;
-  d.n_tiles = ceil_div(d.Cout, 128);
+  constexpr int lds = STAGES * (BCO + RING_PX) * 128;
+  d.n_tiles = ceil_div(d.Cout, BCO);
   const long long tiles = px_tiles * d.n_tiles;
   if (tiles >= 2147483647LL) {
     set_error("conv: too many tiles");
@@ -1972,9 +2150,9 @@ static int launch_ring(ConvDev& d, hipStream_t st, int batch, long long px_tiles
     if (grid < 8) grid = 8;
   }
   static LdsConfigured configured;  // per instantiation
-  int rc = set_lds(conv_fwd_ring_kernel<TO, STAGES, MW, LW>, lds, "conv_fwd_ring", configured);
+  int rc = set_lds(conv_fwd_ring_kernel<TO, STAGES, MW, LW, BCO>, lds, "conv_fwd_ring", configured);
   if (rc != SEGK_OK) return rc;
-  conv_fwd_ring_kernel<TO, STAGES, MW, LW><<<dim3((unsigned)grid, (unsigned)batch), 64 * (LW + MW), lds, st>>>(d);
+  conv_fwd_ring_kernel<TO, STAGES, MW, LW, BCO><<<dim3((unsigned)grid, (unsigned)batch), 64 * (LW + MW), lds, st>>>(d);
   return SEGK_OK;
 }
 
@@ -2405,11 +2583,22 @@ struct TilePlan {
 // Experiment builds keep three other forms for comparison (SEGK_CONV_RING=2: two stages, four multipliers of 64 x 80,
 // two workgroups per CU - level on the large launches, 40 % slower on launches of one workgroup per CU; 3: four
 // stages - level; 4: eight loading wavefronts - level: the K loop is not bound by the loaders' instruction issue).
+// Form 6 is the same kernel on 256(co) x 160(px) tiles (64 x 80 per multiplying wavefront): half the barriers, 0.72 of
+// the LDS-DMA bytes and 0.64 of the fragment reads per MFMA, but half as many tiles to spread over the CUs.  It is
+// taken when the output channels fill 256-wide tiles and the rounds of workgroups (one per CU, each walking over
+// ceil(tiles / CUs) tiles) cost less that way; RING_WIDE_STEP is the time of a K step of the wide tile relative to
+// two steps of the narrow one.
+constexpr double RING_WIDE_STEP = 0.82;
 static int ring_form(const ConvDev& d, bool wide, bool bf16, int batch) {
   if (!wide || !bf16) return 0;
   static const char* e = experiment("SEGK_CONV_RING");
+  if (e && e[0] == '6') return d.Cout % 256 == 0 ? 6 : 1;
   if (e) return e[0] >= '1' && e[0] <= '5' ? e[0] - '0' : 0;
-  return 1;
+  if (d.Cout % 256 != 0) return 1;
+  const long long px_tiles = (d.M + RING_PX - 1) / RING_PX, cus = cu_count();
+  const long long narrow = px_tiles * (d.Cout / 128) * batch, wider = px_tiles * (d.Cout / 256) * batch;
+  const double t_narrow = (double)((narrow + cus - 1) / cus), t_wide = 2.0 * RING_WIDE_STEP * (double)((wider + cus - 1) / cus);
+  return t_wide < t_narrow ? 6 : 1;
 }
 
 static TilePlan plan_tiles(const ConvDev& d, bool wide, int batch, bool bf16) {
@@ -2570,7 +2759,11 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
     else if (f == 5) rc = SEGK_RING(3, 4, 4);
     else
 #endif
-    rc = SEGK_RING(3, 8, 4);
+    if (f == 6)
+      rc = a->out_dtype == SEGK_BF16 ? launch_ring<bf16_t, 3, 8, 4, 256>(d, st, batch, plan.main_tiles)
+                                     : launch_ring<float, 3, 8, 4, 256>(d, st, batch, plan.main_tiles);
+    else
+      rc = SEGK_RING(3, 8, 4);
 #undef SEGK_RING
     if (rc != SEGK_OK) return rc;
     SEGK_CHECK_LAUNCH("conv_fwd");

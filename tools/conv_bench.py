@@ -47,7 +47,10 @@ def main():
            ("feeder l4 3x3 d4", 33, 512, 512, 512, 3, 4),
            # same map and output width, growing K: the slope is the cost of a K step, the intercept the fixed part
            ("probe k 3x3 c64", 33, 64, 64, 256, 3, 1), ("probe k 3x3 c128", 33, 128, 128, 256, 3, 1),
-           ("probe k 3x3 c512", 33, 512, 512, 256, 3, 1), ("probe k 3x3 c1024", 33, 1024, 1024, 256, 3, 1)]
+           ("probe k 3x3 c512", 33, 512, 512, 256, 3, 1), ("probe k 3x3 c1024", 33, 1024, 1024, 256, 3, 1),
+           # the decoder's map (several tiles per CU), growing K: slope = K step, intercept = the tiles' fixed cost
+           ("probe d 3x3 c64", 129, 64, 64, 256, 3, 1), ("probe d 3x3 c128", 129, 128, 128, 256, 3, 1),
+           ("probe d 3x3 c512", 129, 512, 512, 256, 3, 1)]
     for name, H, cin, cpad, cout, R, dil in fwd:
         if args.only and args.only not in name:
             continue
