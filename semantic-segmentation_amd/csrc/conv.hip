@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <type_traits>
 #include <cstdio>
 #include "common.h"
 
@@ -1872,69 +1873,59 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
       u32x4 fb[2][MJ];   // [half of the step]
       u32x4 fa[2][2];    // [unit parity][block of the pair]
       auto read_b = [&](int ks) {
-#ifdef SEGK_EXPERIMENTS
-        if (p.abl & 2) return;             // timing experiment: loads and barriers only
-#endif
         const char* b = smem + stage * STAGE_B + BCO * 128;
 #pragma unroll
         for (int j = 0; j < MJ; ++j)
           fb[ks][j] = *reinterpret_cast<const u32x4*>(b + tile_off<BKB>(wc * (MJ * 16) + j * 16 + frow, ks * 4 + fg));
       };
       auto read_a = [&](int buf, int pair, int ks) {
-#ifdef SEGK_EXPERIMENTS
-        if (p.abl & 2) return;
-#endif
         const char* a = smem + stage * STAGE_B;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
           fa[buf][i] = *reinterpret_cast<const u32x4*>(a + tile_off<BKB>(wr * 64 + (pair * 2 + i) * 16 + frow, ks * 4 + fg));
         __builtin_amdgcn_sched_barrier(0);   // the reads are issued here, not after the MFMAs that follow
       };
-      auto unit = [&](int buf, int pair, int ks) {
-#ifdef SEGK_EXPERIMENTS
-        if (p.abl & (2 | 128)) return;     // timing experiments: ... and fragment reads without the MFMAs (128)
-#endif
+      auto half_unit = [&](int buf, int pair, int ks, int i) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < MJ; ++j) Mma<bf16_t>::run(fa[buf][i], fb[ks][j], acc[pair * 2 + i][j]);
+        for (int j = 0; j < MJ; ++j) Mma<bf16_t>::run(fa[buf][i], fb[ks][j], acc[pair * 2 + i][j]);
         __builtin_amdgcn_sched_barrier(0);
       };
-      if (total > 0) {
+      // The two multiplying wavefronts of a SIMD (wave and wave + 4) leave every barrier together; were their
+      // streams identical, both would issue fragment reads at the same moments and both MFMA bursts would collide.
+      // The second group therefore issues the reads of the next unit in the middle of its MFMAs instead of in
+      // front of them: one group's reads fall into the other's MFMAs.
+      auto k_loop = [&](auto late_tag) {
+        constexpr bool LATE = decltype(late_tag)::value;
+        // one unit: wait for its fragments, issue the reads `next` of the unit after it, ten MFMAs
+        auto unit = [&](int buf, int pair, int ks, auto next) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (!LATE) next();
+          half_unit(buf, pair, ks, 0);
+          if (LATE) next();
+          half_unit(buf, pair, ks, 1);
+        };
         bare_barrier();
         read_b(0);
         read_a(0, 0, 0);
         for (int st = 0; st + 1 < total; ++st) {
+          unit(0, 0, 0, [&] { read_a(1, 1, 0); });
+          unit(1, 1, 0, [&] { read_b(1); read_a(0, 0, 1); });
+          unit(0, 0, 1, [&] { read_a(1, 1, 1); });
+          // (the wait in front of this unit: every read of step st is complete, its stage is free)
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          read_a(1, 1, 0);
-          unit(0, 0, 0);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          read_b(1);
-          read_a(0, 0, 1);
-          unit(1, 1, 0);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          read_a(1, 1, 1);
-          unit(0, 0, 1);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of step st is complete: its stage is free
           stage = stage == STAGES - 1 ? 0 : stage + 1;
           bare_barrier();
-          read_b(0);
-          read_a(0, 0, 0);
-          unit(1, 1, 1);
+          unit(1, 1, 1, [&] { read_b(0); read_a(0, 0, 0); });
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        read_a(1, 1, 0);
-        unit(0, 0, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        read_b(1);
-        read_a(0, 0, 1);
-        unit(1, 1, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        read_a(1, 1, 1);
-        unit(0, 0, 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        unit(0, 0, 0, [&] { read_a(1, 1, 0); });
+        unit(1, 1, 0, [&] { read_b(1); read_a(0, 0, 1); });
+        unit(0, 0, 1, [&] { read_a(1, 1, 1); });
+        unit(1, 1, 1, [&] {});
         stage = stage == STAGES - 1 ? 0 : stage + 1;
-        unit(1, 1, 1);
+      };
+      if (total > 0) {
+        if (wave < MW / 2) k_loop(std::false_type{});
+        else k_loop(std::true_type{});
       }
     } else if (MW == 8 || STAGES == 3) {
       // Fragment reads run one half step (32 channels) ahead of the MFMAs: while the MFMAs of one half run, the next
@@ -1957,36 +1948,44 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
           fa[buf][i] = *reinterpret_cast<const u32x4*>(a + tile_off<BKB>(wr * (MI * 16) + i * 16 + frow, ks * 4 + fg));
         __builtin_amdgcn_sched_barrier(0);   // the reads are issued here, not after the MFMAs that follow
       };
-      auto mfmas = [&](int buf) {
+      auto mfma_block = [&](int buf, int i) {
 #ifdef SEGK_EXPERIMENTS
         if (p.abl & (2 | 128)) return;     // timing experiments: ... and fragment reads without the MFMAs (128)
 #endif
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < MJ; ++j) Mma<bf16_t>::run(fa[buf][i], fb[buf][j], acc[i][j]);
+        for (int j = 0; j < MJ; ++j) Mma<bf16_t>::run(fa[buf][i], fb[buf][j], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
       };
-      if (total > 0) {
+      // (the second group of multiplying wavefronts - the SIMD partners of the first - issues the next half's reads
+      // after the first of its MFMA blocks instead of in front of them: see the 256-channel form above)
+      auto k_loop = [&](auto late_tag) {
+        constexpr bool LATE = decltype(late_tag)::value;
+        auto half = [&](int buf, auto next) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (!LATE) next();
+          mfma_block(buf, 0);
+          if (LATE) next();
+#pragma unroll
+          for (int i = 1; i < MI; ++i) mfma_block(buf, i);
+        };
         bare_barrier();
         read_half(0, 0);
         // (the last step is peeled off: were its missing barrier and reads a branch inside the loop, the compiler's
         // counted waits in front of the MFMAs would have to assume the path without reads and wait for all of them)
         for (int st = 0; st + 1 < total; ++st) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          read_half(1, 1);
-          stage = stage == STAGES - 1 ? 0 : stage + 1;
-          mfmas(0);
+          half(0, [&] { read_half(1, 1); });
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of step st is complete: its stage is free
+          stage = stage == STAGES - 1 ? 0 : stage + 1;
           bare_barrier();
-          read_half(0, 0);
-          mfmas(1);
+          half(1, [&] { read_half(0, 0); });
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        read_half(1, 1);
+        half(0, [&] { read_half(1, 1); });
+        half(1, [&] {});
         stage = stage == STAGES - 1 ? 0 : stage + 1;
-        mfmas(0);
-        mfmas(1);
+      };
+      if (total > 0) {
+        if (wave < MW / 2) k_loop(std::false_type{});
+        else k_loop(std::true_type{});
       }
     } else {
       for (int st = 0; st < total; ++st) {
