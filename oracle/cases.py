@@ -21,7 +21,8 @@ class Impl:
 
     def __init__(self, Branch, ASPP, Decoder, ce_loss, Evaluator, DeepLab=None, BatchNorm=nn.BatchNorm2d,
                  interpolate=None, lr_groups=None, device="cpu", name="impl", PAM=None, CAM=None, DAMM=None,
-                 DeepLabDAMM=None, focal_loss=None, class_weights=None, optimizer=None, scheduler=None):
+                 DeepLabDAMM=None, focal_loss=None, class_weights=None, optimizer=None, scheduler=None,
+                 dropout_masks=None):
         self.Branch = Branch          # (inplanes, planes, k, padding, dilation, BatchNorm)
         self.ASPP = ASPP              # (backbone, output_stride, BatchNorm)
         self.Decoder = Decoder        # (num_classes, backbone, BatchNorm)
@@ -45,6 +46,9 @@ class Impl:
         # (mode, base_lr, num_epochs, iters_per_epoch) -> callable(optimizer, i, epoch, best_pred); None: the poly
         # formula written out in case_e2e
         self.scheduler = scheduler
+        # (list of NCHW keep-masks) -> context manager under which the implementation's training-mode dropouts take
+        # these masks in evaluation order; None: the implementation draws its own (the reference: torch's generator)
+        self.dropout_masks = dropout_masks
 
 
 def _t(a, device, grad=False):
@@ -158,6 +162,69 @@ def case_decoder(impl, num_classes=21, shape_x=(2, 5, 7), shape_low=(2, 17, 25))
         for name, p in m.named_parameters():
             g = _np(p.grad)
             out[mode + "_d/" + name] = g if g.size <= 4096 else _sample(g)
+    return out
+
+
+# ----------------------------------------------------- (3b) dropout switched on ----
+DROPOUT_KINDS = ["aspp", "decoder"]
+DROPOUT_SEED = 4711
+
+
+def unpack_masks(golden):
+    """The keep-masks a dropout fixture recorded, as bool tensors in evaluation order."""
+    masks = []
+    i = 0
+    while "mask%d" % i in golden:
+        shape = tuple(int(v) for v in golden["mask%d_shape" % i])
+        bits = np.unpackbits(golden["mask%d" % i])[:int(np.prod(shape))]
+        masks.append(torch.from_numpy(bits.reshape(shape).astype(np.bool_)))
+        i += 1
+    return masks
+
+
+def case_dropout(impl, kind, masks=None):
+    """ASPP (dropout 0.5 behind its projection, /root/reference/modeling/aspp.py:147) or the decoder (0.5 and 0.1
+    inside last_conv, /root/reference/modeling/decoder.py:146,151) in training mode with dropout ON.
+    masks=None: the implementation draws its own masks from torch's generator, seeded here (the reference, when the
+    fixture is written); the draws are repeated afterwards on tensors of ones and recorded bit-packed in the result.
+    Otherwise the implementation runs on the given masks (impl.dropout_masks)."""
+    tag = "dropout_" + kind
+    if kind == "aspp":
+        n, h, w, inplanes = 4, 9, 11, 320
+        m = _load(impl.ASPP("mobilenet", 16, impl.BatchNorm), SEED, tag, impl.device)
+        inputs = [_t(gen.relu_normal(SEED, tag + "/x", (n, inplanes, h, w)) * _gain(n, inplanes), impl.device, grad=True)]
+        drops = [((n, 256, h, w), m.dropout.p)]
+        names = ["dx"]
+    else:
+        sx, sl = (2, 5, 7), (2, 17, 25)
+        m = _load(impl.Decoder(21, "resnet", impl.BatchNorm), SEED, tag, impl.device)
+        inputs = [_t(gen.relu_normal(SEED, tag + "/x", (sx[0], 256) + sx[1:]) * _gain(sx[0], 256), impl.device, grad=True),
+                  _t(gen.relu_normal(SEED, tag + "/low", (sl[0], 256) + sl[1:]) * _gain(sl[0], 256, "gainlow"),
+                     impl.device, grad=True)]
+        drops = [((sl[0], 256) + sl[1:], m.last_conv[3].p), ((sl[0], 256) + sl[1:], m.last_conv[7].p)]
+        names = ["dx", "dlow"]
+    m.train()
+    out = {}
+    if masks is None:
+        torch.manual_seed(DROPOUT_SEED)
+        y = m(*inputs)
+        # the same draws again: F.dropout of a tensor of ones is the keep-mask over (1 - p)
+        torch.manual_seed(DROPOUT_SEED)
+        for i, (shape, p) in enumerate(drops):
+            keep = (F.dropout(torch.ones(shape), p, True) != 0).numpy()
+            out["mask%d" % i] = np.packbits(keep.reshape(-1))
+            out["mask%d_shape" % i] = np.array(shape, dtype=np.int64)
+    else:
+        with impl.dropout_masks(masks):
+            y = m(*inputs)
+    gy = _t(gen.normal(SEED, tag + "/gy", tuple(y.shape)), impl.device)
+    y.backward(gy)
+    out["y"] = _np(y)
+    for nm, t in zip(names, inputs):
+        out[nm] = _sample(_np(t.grad), 16384)
+    for name, p in m.named_parameters():
+        g = _np(p.grad)
+        out["d/" + name] = g if g.size <= 4096 else _sample(g)
     return out
 
 
@@ -337,9 +404,10 @@ def case_e2e(impl, steps=2, n=4, size=65, K=21, base_lr=0.007, total_iters=100):
 
 
 # ------------------------------------------------- (9) full-size summaries ----
-def case_fullsize(impl, config="A", n=3, backward=True):
+def case_fullsize(impl, config="A", n=3, backward=True, dropout=False):
     """Head only, at BASELINE shapes.  A: OS16 513^2 K=21 (x 33^2, low 129^2);
-    D: OS8 769^2 K=19 (x 97^2, low 193^2)."""
+    D: OS8 769^2 K=19 (x 97^2, low 193^2).  dropout: the three dropouts stay at their probabilities (0.5, 0.5, 0.1)
+    and take keep-masks from the portable generator (needs impl.dropout_masks)."""
     if config == "A":
         os_, h, l, H, K = 16, 33, 129, 513, 21
     else:
@@ -348,13 +416,22 @@ def case_fullsize(impl, config="A", n=3, backward=True):
     aspp = _load(impl.ASPP("resnet", os_, impl.BatchNorm), SEED, tag + "/aspp", impl.device)
     dec = _load(impl.Decoder(K, "resnet", impl.BatchNorm), SEED, tag + "/dec", impl.device)
     for m in (aspp, dec):
-        _zero_dropout(m)
+        if not dropout:
+            _zero_dropout(m)
         m.train()
     x = _t(gen.relu_normal(SEED, tag + "/x", (n, 2048, h, h)) * _gain(n, 2048), impl.device, grad=backward)
     low = _t(gen.relu_normal(SEED, tag + "/low", (n, 256, l, l)) * _gain(n, 256, "gainlow"), impl.device, grad=backward)
     target = _t(gen.labels(SEED, tag + "/lab", (n, H, H), K, border=10), impl.device)
-    a = aspp(x)
-    d = dec(a, low)
+    if dropout:
+        ps = (aspp.dropout.p, dec.last_conv[3].p, dec.last_conv[7].p)
+        shapes = ((n, 256, h, h), (n, 256, l, l), (n, 256, l, l))
+        masks = [torch.from_numpy(gen.uniform(SEED, tag + "/drop%d" % i, shp) >= p) for i, (shp, p) in enumerate(zip(shapes, ps))]
+        with impl.dropout_masks(masks):
+            a = aspp(x)
+            d = dec(a, low)
+    else:
+        a = aspp(x)
+        d = dec(a, low)
     logits = impl.interpolate(d, (H, H))
     loss = impl.ce_loss(logits, target, None)
     out = {"loss": _np(loss).reshape(1), "aspp_chan_sum": _np(a.sum(dim=(0, 2, 3))),

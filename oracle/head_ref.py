@@ -97,6 +97,46 @@ class record_relu_masks:
         _RECORD = None
 
 
+# ---- optional externally supplied dropout masks ------------------------------------------------
+# nn.Dropout draws its mask from torch's generator, which another implementation cannot reproduce.  With masks set
+# (use_dropout_masks), every training-mode dropout of the Ref* modules with 0 < p < 1 takes the next one, in call
+# order, and computes what F.dropout computes for that draw: x * keep / (1 - p).
+_DROP_MASKS = None
+
+
+class _Dropout(nn.Dropout):
+    def forward(self, x):
+        if _DROP_MASKS is None or not self.training or not 0.0 < self.p < 1.0:
+            return super().forward(x)
+        keep = _DROP_MASKS.pop(0)
+        assert tuple(keep.shape) == tuple(x.shape), (tuple(keep.shape), tuple(x.shape))
+        if _RECORD:
+            # every dropout of these modules follows a ReLU directly: the recorded pattern of that ReLU becomes the
+            # pattern of what leaves the dropout (what an implementation that fuses the two can report)
+            _RECORD[-1] = _RECORD[-1] & (keep != 0).cpu()
+        return x * (keep.to(device=x.device) != 0).to(x.dtype) * (1.0 / (1.0 - self.p))
+
+
+class use_dropout_masks:
+    """Context manager: the next training-mode dropouts of the Ref* modules keep exactly the elements these masks
+    name (NCHW-shaped, non-zero = keep), in call order."""
+
+    def __init__(self, masks):
+        self.masks = list(masks)
+
+    def __enter__(self):
+        global _DROP_MASKS
+        _DROP_MASKS = self.masks
+        return self
+
+    def __exit__(self, *exc):
+        global _DROP_MASKS
+        left = len(_DROP_MASKS) if _DROP_MASKS is not None else 0
+        _DROP_MASKS = None
+        if exc[0] is None and left:
+            raise AssertionError("%d dropout masks were not consumed" % left)
+
+
 class _ReLU(nn.Module):
     def forward(self, x):
         return _relu(x)
@@ -135,7 +175,7 @@ class RefASPP(nn.Module):
             nn.AdaptiveAvgPool2d((1, 1)), nn.Conv2d(inplanes, planes, 1, bias=False), BatchNorm(planes), _ReLU())
         self.conv1 = nn.Conv2d(5 * planes, planes, 1, bias=False)
         self.bn1 = BatchNorm(planes)
-        self.dropout = nn.Dropout(0.5)
+        self.dropout = _Dropout(0.5)
         _reset(self)
 
     def forward(self, x):
@@ -155,8 +195,8 @@ class RefDecoder(nn.Module):
         self.conv1 = nn.Conv2d(low_level_inplanes, 48, 1, bias=False)
         self.bn1 = BatchNorm(48)
         self.last_conv = nn.Sequential(
-            nn.Conv2d(aspp_planes + 48, planes, 3, 1, 1, bias=False), BatchNorm(planes), _ReLU(), nn.Dropout(0.5),
-            nn.Conv2d(planes, planes, 3, 1, 1, bias=False), BatchNorm(planes), _ReLU(), nn.Dropout(0.1),
+            nn.Conv2d(aspp_planes + 48, planes, 3, 1, 1, bias=False), BatchNorm(planes), _ReLU(), _Dropout(0.5),
+            nn.Conv2d(planes, planes, 3, 1, 1, bias=False), BatchNorm(planes), _ReLU(), _Dropout(0.1),
             nn.Conv2d(planes, num_classes, 1))
         _reset(self)
 

@@ -26,6 +26,11 @@ _BN_TYPES = (torch.nn.modules.batchnorm._BatchNorm,)
 # activation pattern the kernels produced.  None in normal operation.
 CAPTURE = None
 
+# Test hook: when set to a list of keep-masks (NCHW-shaped, non-zero = keep), every training-mode dropout with
+# 0 < p < 1 takes the next one instead of drawing from torch's generator, in evaluation order (ASPP's, then the
+# decoder's two), so that another implementation can be run on the same masks.  None in normal operation.
+DROPOUT_MASKS = None
+
 
 # ------------------------------------------------------------------ views ----
 def pm_view_of(t):
@@ -140,11 +145,19 @@ class _UnitRecord:
                  "Cin", "weight")
 
 
-def _dropout_mask(shape, p, device):
+def _dropout_mask(shape, p, device, geom=None):
+    """(uint8 keep-mask of `shape` = [pixels, channels] or None, scale of the kept elements)."""
     if p <= 0.0:
         return None, 1.0
     if p >= 1.0:
         return torch.zeros(shape, dtype=torch.uint8, device=device), 0.0
+    if DROPOUT_MASKS is not None:
+        given = DROPOUT_MASKS.pop(0)
+        N, H, W = geom
+        if tuple(given.shape) != (N, shape[1], H, W):
+            raise ValueError("injected dropout mask has shape %s, expected %s" % (tuple(given.shape), (N, shape[1], H, W)))
+        keep = (given.to(device) != 0).permute(0, 2, 3, 1).reshape(shape)
+        return keep.to(torch.uint8).contiguous(), 1.0 / (1.0 - p)
     keep = torch.rand(shape, device=device) >= p
     return keep.to(torch.uint8), 1.0 / (1.0 - p)
 
@@ -176,7 +189,7 @@ def unit_finish(x, raw, stats, weight, R, dil, geom, spec, gamma, beta, out, rel
         coef = ops.bn_coeffs_eval(spec.running_mean, spec.running_var, gamma, beta, spec.eps)
     mask, mask_scale = (None, 1.0)
     if drop_training and drop_p > 0.0:
-        mask, mask_scale = _dropout_mask((M, Cout), drop_p, x.device)
+        mask, mask_scale = _dropout_mask((M, Cout), drop_p, x.device, geom)
     ops.bn_apply(raw, out, coef, PM, relu, mask, mask_scale)
     if CAPTURE is not None:
         CAPTURE.append((out, geom))

@@ -28,6 +28,20 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / scale)
 
 
+def rel_elementwise(a, b, floor=1e-3):
+    """Largest |a-b| / |b| over the elements with |b| > floor * max|b| (the element-wise reading of a relative
+    tolerance; elements that are small against the tensor's scale have no meaningful relative error), and that
+    element's reference value."""
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    keep = np.abs(b) > floor * np.abs(b).max()
+    if not keep.any():
+        return 0.0, 0.0
+    r = np.abs(a[keep] - b[keep]) / np.abs(b[keep])
+    i = int(np.argmax(r))
+    return float(r[i]), float(b[keep][i])
+
+
 def rel_l2(a, b):
     """||a-b||_2 / ||b||_2."""
     a = np.asarray(a, dtype=np.float64).reshape(-1)

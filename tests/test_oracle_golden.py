@@ -25,7 +25,8 @@ def oracle_impl():
                       lr_groups=lambda m: m.lr_groups(), name="oracle", PAM=damm_ref.RefPAM, CAM=damm_ref.RefCAM,
                       DAMM=damm_ref.RefDAMM, focal_loss=lambda lo, t, w: ops_ref.focal_loss(lo, t, w),
                       class_weights=lambda ds, loader, K: ops_ref.class_weights([b["label"].numpy() for b in loader], K),
-                      DeepLabDAMM=lambda: damm_ref.RefDeepLabDAMM("resnet", 16, 8, nn.BatchNorm2d))
+                      DeepLabDAMM=lambda: damm_ref.RefDeepLabDAMM("resnet", 16, 8, nn.BatchNorm2d),
+                      dropout_masks=head_ref.use_dropout_masks)
 
 
 @pytest.fixture(scope="module")
@@ -51,6 +52,25 @@ def test_aspp_drn_os8(impl):
 @pytest.mark.parametrize("K", [21, 19])
 def test_decoder(impl, K):
     assert_dicts_close(cases.case_decoder(impl, K), load_golden("decoder_k%d" % K), TOL)
+
+
+@pytest.mark.parametrize("kind", cases.DROPOUT_KINDS)
+def test_dropout_on(impl, kind):
+    """Dropout switched ON: the fixture is the reference running its own nn.Dropout from a seeded generator and holds
+    the masks it drew; the oracle's masked twin (x * keep / (1 - p)) on those masks reproduces outputs and gradients."""
+    gold = load_golden("dropout_" + kind)
+    masks = cases.unpack_masks(gold)
+    assert len(masks) == (1 if kind == "aspp" else 2)
+    for m in masks:   # p = 0.5 (and 0.1): the recorded draws are dropout masks, not all-ones
+        assert 0.3 < float(m.float().mean()) < 0.95
+    want = {k: v for k, v in gold.items() if not k.startswith("mask")}
+    assert_dicts_close(cases.case_dropout(impl, kind, masks), want, TOL)
+
+
+def test_dropout_masks_all_consumed(impl):
+    masks = cases.unpack_masks(load_golden("dropout_aspp"))
+    with pytest.raises(AssertionError):
+        cases.case_dropout(impl, "aspp", masks + masks)
 
 
 @pytest.mark.parametrize("i", range(len(cases.INTERP_CFGS)))
