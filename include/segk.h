@@ -335,7 +335,8 @@ int segk_ce_bwd(const float* logits, const float* target, const float* weight, c
  * process ends); the call allocates nothing.  Same results as segk_ce_fwd, bit for bit.  At most
  * segk_ce_fwd_static_max_pixels() = 2^25 pixels (N*HW); more returns SEGK_UNSUPPORTED_SHAPE.  All calls on one
  * GPU share that array: calls that overlap on one GPU (two streams, two threads) race; calls ordered on one
- * stream do not. */
+ * stream do not.  The device the stream belongs to must be the current device (the array's address is looked up
+ * for the current device); a stream of another device returns SEGK_INVALID_ARG. */
 int segk_ce_fwd_static(const float* logits, const float* target, const float* weight, int N, int K, int HW,
                        int ignore_index, float* lse, float* sums, segk_stream_t stream);
 long long segk_ce_fwd_static_max_pixels(void);
@@ -418,6 +419,32 @@ int segk_comm_destroy(void);
 int segk_allreduce_f32(float* buf, long long count, segk_stream_t stream);
 int segk_allreduce_f64(double* buf, long long count, segk_stream_t stream);
 int segk_allreduce_i64(int64_t* buf, long long count, segk_stream_t stream);
+
+/* One-shot all-reduce (in-place SUM) through peer-mapped mailboxes: the latency path for the 226 small exchanges
+ * per training step of the synchronised batch norm - the [sum, sum of squares, count] vector of every layer forward
+ * and [sum g, sum g*xhat] backward - which the reference gathers on replica 0 through Python queues, reduces with
+ * ReduceAddCoalesced and broadcasts back (modeling/sync_batchnorm/batchnorm.py:90-111, comm.py:97-125).  One
+ * single-workgroup kernel per rank stores the vector into every rank's mailbox, waits for the others' and adds
+ * them in rank order, so every rank holds bit-identical sums; no host call, no library collective, and the launch
+ * can be recorded in a HIP graph (its sequence number lives in device memory).
+ *   segk_mailbox_create   allocates this process's mailbox on the current device (fine-grained device memory owned
+ *                         by the library until segk_mailbox_destroy) and writes its IPC handle
+ *                         (SEGK_MAILBOX_HANDLE_BYTES) to handle_out;
+ *   segk_mailbox_connect  takes the `world` handles in rank order (exchanged by the host by any means), maps the
+ *                         peers' mailboxes; timeout_ms bounds every in-kernel wait (<= 0: 60 000);
+ *   segk_mailbox_allreduce_f64 / _f32: buf[0..n) on the device, any n (vectors longer than SEGK_MAILBOX_MAX_DOUBLES
+ *                         go through in chunks inside the one launch; sums are formed in fp64 and rounded once);
+ *                         every rank must issue the same sequence of calls;
+ *   segk_mailbox_status   synchronous: the number of exchanges completed so far, or a negative status when an
+ *                         in-kernel wait timed out (results from then on are not sums). */
+#define SEGK_MAILBOX_HANDLE_BYTES 64
+#define SEGK_MAILBOX_MAX_DOUBLES 4352
+int segk_mailbox_create(int world, void* handle_out);
+int segk_mailbox_connect(int rank, int world, const void* handles, int timeout_ms);
+int segk_mailbox_allreduce_f64(double* buf, long long n, segk_stream_t stream);
+int segk_mailbox_allreduce_f32(float* buf, long long n, segk_stream_t stream);
+long long segk_mailbox_status(void);
+int segk_mailbox_destroy(void);
 
 #ifdef __cplusplus
 }

@@ -106,3 +106,221 @@ extern "C" int segk_allreduce_f64(double* buf, long long count, segk_stream_t st
 extern "C" int segk_allreduce_i64(int64_t* buf, long long count, segk_stream_t stream) {
   return all_reduce_sum(buf, count, RCCL_INT64, stream);
 }
+
+// ------------------------------------------------------------------------------------------------
+// One-shot all-reduce through peer-mapped mailboxes, for the small vectors a synchronised batch norm exchanges
+// ([2C+1] fp64, at most 32 KiB) where a library collective is pure latency: 226 of them per training step.
+// Every rank owns one allocation (fine-grained device memory, shared with the other processes by IPC handle):
+//   flags[2][MAX_WORLD]   the sequence number of the last vector rank q has delivered into slot [phase][q]
+//   counter, status       this rank's own sequence number; non-zero status = a wait ran out of time
+//   slots[2][world][MBX_MAX_DOUBLES]
+// One exchange = one single-workgroup kernel per rank: store the vector into slot [phase][rank] of EVERY rank's
+// mailbox (its own included), release, raise flag [phase][rank] there to the exchange's sequence number; wait until
+// the own mailbox holds that number from every rank; add the slots in rank order (every rank computes the same
+// bits).  phase = sequence number & 1: a rank can be one exchange ahead of a peer, never two - it needs the peer's
+// flag of exchange k + 1 to finish k + 1, and the peer raises that only after it has read exchange k - so two slots
+// per rank suffice.  The sequence number lives in device memory and advances inside the kernel, so a launch
+// recorded in a HIP graph stays correct when it is replayed.  Longer vectors go through in chunks, one exchange
+// each, inside the same launch.  Every wait is bounded (default 60 s); when it runs out the kernel records the
+// sequence number in `status` and ends, and segk_mailbox_status() reports it.
+// ------------------------------------------------------------------------------------------------
+namespace segk {
+
+constexpr int MBX_MAX_WORLD = 16;
+constexpr int MBX_HEADER_BYTES = 512;
+constexpr int MBX_THREADS = 1024;
+
+struct MailboxPeers {
+  char* base[MBX_MAX_WORLD];
+  int rank, world;
+  unsigned long long timeout_ticks;   // of the 100 MHz constant clock
+};
+
+static struct {
+  char* own;            // this rank's allocation
+  void* opened[MBX_MAX_WORLD];
+  MailboxPeers peers;
+  bool connected;
+} g_mbx = {};
+
+static size_t mailbox_bytes(int world) {
+  return (size_t)MBX_HEADER_BYTES + (size_t)2 * world * SEGK_MAILBOX_MAX_DOUBLES * sizeof(double);
+}
+
+__device__ __forceinline__ unsigned long long* mbx_flag(char* base, int phase, int q) {
+  return reinterpret_cast<unsigned long long*>(base) + phase * MBX_MAX_WORLD + q;
+}
+__device__ __forceinline__ double* mbx_slot(char* base, int world, int phase, int q) {
+  return reinterpret_cast<double*>(base + MBX_HEADER_BYTES) + ((size_t)phase * world + q) * SEGK_MAILBOX_MAX_DOUBLES;
+}
+
+template <typename T>
+__global__ __launch_bounds__(MBX_THREADS) void mailbox_allreduce_kernel(const MailboxPeers a, T* buf, long long n) {
+  __shared__ unsigned long long s_seq0;
+  __shared__ int s_fail;
+  const int tid = threadIdx.x;
+  char* const own = a.base[a.rank];
+  unsigned long long* const counter = reinterpret_cast<unsigned long long*>(own) + 2 * MBX_MAX_WORLD;
+  unsigned long long* const status = counter + 1;
+  if (tid == 0) {
+    s_seq0 = *counter;
+    s_fail = 0;
+  }
+  __syncthreads();
+  const unsigned long long seq0 = s_seq0;
+  const long long chunks = (n + SEGK_MAILBOX_MAX_DOUBLES - 1) / SEGK_MAILBOX_MAX_DOUBLES;
+  long long done = 0;
+  for (long long c = 0; c < chunks; ++c) {
+    const unsigned long long seq = seq0 + 1 + (unsigned long long)c;
+    const int phase = (int)(seq & 1ull);
+    T* const part = buf + c * SEGK_MAILBOX_MAX_DOUBLES;
+    const int cn = (int)((n - c * SEGK_MAILBOX_MAX_DOUBLES) < SEGK_MAILBOX_MAX_DOUBLES ? (n - c * SEGK_MAILBOX_MAX_DOUBLES)
+                                                                                   : SEGK_MAILBOX_MAX_DOUBLES);
+    // deliver: this rank's values into its slot of every mailbox, write-through at system scope
+    for (int p = 0; p < a.world; ++p) {
+      double* dst = mbx_slot(a.base[p], a.world, phase, a.rank);
+      for (int i = tid; i < cn; i += MBX_THREADS)
+        __hip_atomic_store(dst + i, (double)part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid < a.world)
+      __hip_atomic_store(mbx_flag(a.base[tid], phase, a.rank), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // wait for every rank's delivery into the own mailbox (bounded)
+    if (tid < a.world) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      unsigned long long* f = mbx_flag(own, phase, tid);
+      while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+        __builtin_amdgcn_s_sleep(8);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
+          atomicExch(&s_fail, 1);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    if (s_fail) {
+      if (tid == 0) __hip_atomic_store(status, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+    __threadfence_system();
+    // the sum, in rank order on every rank
+    for (int i = tid; i < cn; i += MBX_THREADS) {
+      double s = 0.0;
+      for (int q = 0; q < a.world; ++q)
+        s += __hip_atomic_load(mbx_slot(own, a.world, phase, q) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      part[i] = (T)s;
+    }
+    done = c + 1;
+    __syncthreads();
+  }
+  // (also after a failure: the exchanges that did complete stay counted, so that the ranks' numbers keep agreeing
+  // for whoever inspects them)
+  if (tid == 0) *counter = seq0 + (unsigned long long)done;
+}
+
+static int mailbox_launch_check(const void* buf, long long n) {
+  SEGK_REQUIRE(g_mbx.connected, "mailbox: segk_mailbox_connect has not been called");
+  SEGK_REQUIRE(buf && n > 0, "mailbox: null pointer or count=%lld", n);
+  return SEGK_OK;
+}
+
+}  // namespace segk
+
+extern "C" int segk_mailbox_create(int world, void* handle_out) {
+  SEGK_REQUIRE(handle_out && world >= 1 && world <= MBX_MAX_WORLD, "mailbox_create: world=%d (1..%d)", world, MBX_MAX_WORLD);
+  SEGK_REQUIRE(!g_mbx.own, "mailbox_create: this process already has a mailbox");
+  static_assert(sizeof(hipIpcMemHandle_t) <= SEGK_MAILBOX_HANDLE_BYTES, "IPC handle larger than the ABI's buffer");
+  static_assert((2 * MBX_MAX_WORLD + 2) * sizeof(unsigned long long) <= MBX_HEADER_BYTES, "mailbox header too small");
+  void* p = nullptr;
+  const size_t bytes = mailbox_bytes(world);
+  hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+  if (e != hipSuccess) {
+    set_error("mailbox_create: hipExtMallocWithFlags(%zu, fine-grained) failed: %s", bytes, hipGetErrorString(e));
+    return SEGK_HIP_ERROR;
+  }
+  e = hipMemset(p, 0, bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  hipIpcMemHandle_t h;
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+  if (e != hipSuccess) {
+    set_error("mailbox_create: %s", hipGetErrorString(e));
+    (void)hipFree(p);
+    return SEGK_HIP_ERROR;
+  }
+  memset(handle_out, 0, SEGK_MAILBOX_HANDLE_BYTES);
+  memcpy(handle_out, &h, sizeof(h));
+  g_mbx.own = (char*)p;
+  g_mbx.peers.world = world;
+  return SEGK_OK;
+}
+
+extern "C" int segk_mailbox_connect(int rank, int world, const void* handles, int timeout_ms) {
+  SEGK_REQUIRE(g_mbx.own && !g_mbx.connected, "mailbox_connect: call segk_mailbox_create first (once)");
+  SEGK_REQUIRE(handles && world == g_mbx.peers.world && rank >= 0 && rank < world, "mailbox_connect: rank=%d world=%d", rank, world);
+  for (int q = 0; q < world; ++q) {
+    if (q == rank) {
+      g_mbx.peers.base[q] = g_mbx.own;
+      continue;
+    }
+    hipIpcMemHandle_t h;
+    memcpy(&h, (const char*)handles + (size_t)q * SEGK_MAILBOX_HANDLE_BYTES, sizeof(h));
+    void* p = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      set_error("mailbox_connect: hipIpcOpenMemHandle of rank %d's mailbox failed: %s", q, hipGetErrorString(e));
+      for (int r = 0; r < q; ++r)
+        if (g_mbx.opened[r]) {
+          (void)hipIpcCloseMemHandle(g_mbx.opened[r]);
+          g_mbx.opened[r] = nullptr;
+        }
+      return SEGK_HIP_ERROR;
+    }
+    g_mbx.opened[q] = p;
+    g_mbx.peers.base[q] = (char*)p;
+  }
+  g_mbx.peers.rank = rank;
+  g_mbx.peers.timeout_ticks = (unsigned long long)(timeout_ms > 0 ? timeout_ms : 60000) * 100000ull;
+  g_mbx.connected = true;
+  return SEGK_OK;
+}
+
+extern "C" int segk_mailbox_allreduce_f64(double* buf, long long n, segk_stream_t stream) {
+  int rc = mailbox_launch_check(buf, n);
+  if (rc != SEGK_OK) return rc;
+  mailbox_allreduce_kernel<double><<<1, MBX_THREADS, 0, (hipStream_t)stream>>>(g_mbx.peers, buf, n);
+  SEGK_CHECK_LAUNCH("mailbox_allreduce_f64");
+  return SEGK_OK;
+}
+
+extern "C" int segk_mailbox_allreduce_f32(float* buf, long long n, segk_stream_t stream) {
+  int rc = mailbox_launch_check(buf, n);
+  if (rc != SEGK_OK) return rc;
+  mailbox_allreduce_kernel<float><<<1, MBX_THREADS, 0, (hipStream_t)stream>>>(g_mbx.peers, buf, n);
+  SEGK_CHECK_LAUNCH("mailbox_allreduce_f32");
+  return SEGK_OK;
+}
+
+extern "C" long long segk_mailbox_status(void) {
+  if (!g_mbx.own) return 0;
+  unsigned long long st[2] = {0, 0};   // counter, status
+  if (hipMemcpy(st, g_mbx.own + 2 * MBX_MAX_WORLD * sizeof(unsigned long long), sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) {
+    set_error("mailbox_status: cannot read the mailbox");
+    return SEGK_HIP_ERROR;
+  }
+  if (st[1] != 0) {
+    set_error("mailbox: exchange %llu timed out waiting for a rank (a peer is gone, or ranks issued different exchanges)", st[1]);
+    return SEGK_RCCL_ERROR;
+  }
+  return (long long)st[0];
+}
+
+extern "C" int segk_mailbox_destroy(void) {
+  if (!g_mbx.own) return SEGK_OK;
+  (void)hipDeviceSynchronize();
+  for (int q = 0; q < MBX_MAX_WORLD; ++q)
+    if (g_mbx.opened[q]) (void)hipIpcCloseMemHandle(g_mbx.opened[q]);
+  (void)hipFree(g_mbx.own);
+  g_mbx = {};
+  return SEGK_OK;
+}

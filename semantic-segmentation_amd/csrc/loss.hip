@@ -252,13 +252,23 @@ constexpr int MAX_DEVICES = 64;
 std::mutex g_scratch_mu;
 float* g_scratch_ptr[MAX_DEVICES] = {};
 
-// Address of this device's copy of `scratch` (looked up on the first call per device, under a mutex).
-int scratch_for_current_device(float** out) {
+// Address of this device's copy of `scratch` (looked up on the first call per device, under a mutex).  The lookup
+// answers for the CURRENT device, the launch goes to the stream's: a stream of another device is refused.
+int scratch_for_current_device(float** out, hipStream_t st) {
   int dev = -1;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
     set_error("ce_fwd_static: hipGetDevice: %s (device %d)", hipGetErrorString(e), dev);
     return SEGK_HIP_ERROR;
+  }
+  if (st) {
+    hipDevice_t sdev = -1;
+    e = hipStreamGetDevice(st, &sdev);
+    if (e == hipSuccess && (int)sdev != dev) {
+      set_error("ce_fwd_static: the stream belongs to device %d but device %d is current; make the stream's device "
+                "current before the call", (int)sdev, dev);
+      return SEGK_INVALID_ARG;
+    }
   }
   std::lock_guard<std::mutex> lock(g_scratch_mu);
   if (!g_scratch_ptr[dev]) {
@@ -286,10 +296,10 @@ extern "C" int segk_ce_fwd_static(const float* logits, const float* target, cons
                    "ce_fwd_static: %lld pixels exceed the %lld this entry point's fixed scratch serves; use "
                    "segk_ce_fwd with a caller workspace", P, CE_STATIC_MAX_PIXELS);
   float* part = nullptr;
-  const int rc = scratch_for_current_device(&part);
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = scratch_for_current_device(&part, st);
   if (rc != SEGK_OK) return rc;
   const int rows = ce_rows(P);
-  hipStream_t st = (hipStream_t)stream;
   // every row below `rows` is overwritten by its workgroup and the finish kernel reads only those rows, so the
   // previous call's contents need no clearing
   ce_fwd_kernel<<<rows, CE_THREADS, 0, st>>>(logits, target, weight, K, HW, P, ignore_index, lse, part);

@@ -123,11 +123,17 @@ SIGNATURES = {
     "segk_allreduce_f32": [c_void_p, c_ll, c_void_p],
     "segk_allreduce_f64": [c_void_p, c_ll, c_void_p],
     "segk_allreduce_i64": [c_void_p, c_ll, c_void_p],
+    "segk_mailbox_create": [c_int, c_void_p],
+    "segk_mailbox_connect": [c_int, c_int, c_void_p, c_int],
+    "segk_mailbox_allreduce_f64": [c_void_p, c_ll, c_void_p],
+    "segk_mailbox_allreduce_f32": [c_void_p, c_ll, c_void_p],
+    "segk_mailbox_status": [],
+    "segk_mailbox_destroy": [],
     "segk_sgd_step": [c_void_p, c_int, c_float, c_float, c_float, c_void_p],
     "segk_sgd_step_dev": [c_void_p, c_int, c_void_p, c_void_p],
 }
 _RESTYPES = {"segk_last_error": ctypes.c_char_p, "segk_upsample_bwd_workspace": c_ll,
-             "segk_ce_fwd_static_max_pixels": c_ll}
+             "segk_ce_fwd_static_max_pixels": c_ll, "segk_mailbox_status": c_ll}
 
 _lib = None
 

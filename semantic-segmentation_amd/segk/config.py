@@ -3,7 +3,14 @@ import contextlib
 
 import torch
 
-_state = {"compute_dtype": torch.float32, "legacy_clamp_eps": False, "feeder_conv": "auto", "overlap_wgrad": False}
+import os
+
+_state = {"compute_dtype": torch.float32, "legacy_clamp_eps": False, "feeder_conv": "auto", "overlap_wgrad": False,
+          # debug switches (each costs a host synchronisation or an extra pass where it acts)
+          "debug_packs": os.environ.get("SEGK_DEBUG_PACKS", "") == "1",
+          "debug_labels": os.environ.get("SEGK_DEBUG_LABELS", "") == "1",
+          "debug_sync_stats": os.environ.get("SEGK_DEBUG_SYNC_STATS", "") == "1",
+          "sync_exchange": os.environ.get("SEGK_SYNC_EXCHANGE", "auto")}
 
 
 def set_compute_dtype(dtype):
@@ -90,3 +97,52 @@ def overlap_wgrad_as(flag):
         yield
     finally:
         _state["overlap_wgrad"] = old
+
+
+# ---- debug switches ------------------------------------------------------------------------------------------
+def set_debug_packs(flag):
+    """True (or SEGK_DEBUG_PACKS=1): every use of a kept packed weight operand (segk.ops.cache_weight_packs) packs the
+    weight again and compares; a stale operand - a registered weight changed in place through ``.data``, which moves
+    no version counter - raises instead of giving wrong results silently."""
+    _state["debug_packs"] = bool(flag)
+
+
+def debug_packs():
+    return _state["debug_packs"]
+
+
+def set_debug_labels(flag):
+    """True (or SEGK_DEBUG_LABELS=1): the cross-entropy counts labels that are neither the ignore index nor a class
+    index and raises, as the reference does inside ATen (/root/reference/utils/loss.py:25-30); without it the
+    kernels treat such labels as ignored.  Costs one pass over the labels and a host synchronisation."""
+    _state["debug_labels"] = bool(flag)
+
+
+def debug_labels():
+    return _state["debug_labels"]
+
+
+def set_debug_sync_stats(flag):
+    """True (or SEGK_DEBUG_SYNC_STATS=1): after every exchange of batch-norm statistics between ranks the summed
+    vectors are gathered and compared bit for bit; ranks that normalise with different statistics raise.  (The
+    reference's only guards are the asserts of /root/reference/modeling/sync_batchnorm/comm.py:28,90,115,123.)"""
+    _state["debug_sync_stats"] = bool(flag)
+
+
+def debug_sync_stats():
+    return _state["debug_sync_stats"]
+
+
+def set_sync_exchange(mode):
+    """How ranks exchange the small vectors (batch-norm statistics, loss sums): "auto" - through peer-mapped
+    mailboxes when they can be connected and pass their self-test, else through torch.distributed; "mailbox" -
+    mailboxes or an error; "dist" - torch.distributed always.  Read when the process group is initialised
+    (segk.parallel.init_from_env); environment: SEGK_SYNC_EXCHANGE."""
+    if mode not in ("auto", "mailbox", "dist"):
+        raise ValueError("sync_exchange mode must be 'auto', 'mailbox' or 'dist'")
+    _state["sync_exchange"] = mode
+
+
+def sync_exchange():
+    m = _state["sync_exchange"]
+    return m if m in ("auto", "mailbox", "dist") else "auto"

@@ -120,6 +120,8 @@ def _global_sums(local, sync):
     """All-reduce (SUM) the [2C+1] statistics vector in place across ranks; identity for unsynchronised layers."""
     if sync:
         parallel.all_reduce_sum_(local)
+        if config.debug_sync_stats():
+            parallel.assert_same_on_all_ranks(local, "batch-norm statistics")
     return local
 
 
@@ -202,7 +204,13 @@ def unit_finish(x, raw, stats, weight, R, dil, geom, spec, gamma, beta, out, rel
 
 # ---- weight gradients beside the data-gradient chain (config.set_overlap_wgrad) -------------------------------
 _SIDE_STREAMS = {}   # device index -> the second stream
-_PENDING = []        # (weight, dW, main stream, side stream, tensors the side stream reads) of the running backward
+_PENDING = []        # (weight, dW, main stream, side stream, tensors the side stream reads, backward pass id)
+
+
+def _backward_pass_id():
+    """Identifies the running backward pass (autograd's graph task), -1 outside of one."""
+    f = getattr(torch._C, "_current_graph_task_id", None)
+    return f() if f is not None else -1
 
 
 def _join_weight_grads():
@@ -211,11 +219,11 @@ def _join_weight_grads():
     pending = list(_PENDING)
     del _PENDING[:]
     joined = set()
-    for weight, dw, main, side, _ in pending:
+    for weight, dw, main, side, _, _ in pending:
         if (main, side) not in joined:
             main.wait_stream(side)
             joined.add((main, side))
-    for weight, dw, main, side, _ in pending:
+    for weight, dw, main, side, _, _ in pending:
         with torch.cuda.stream(main), torch.no_grad():
             if weight.grad is None:
                 weight.grad = dw
@@ -244,7 +252,12 @@ def weight_grad(weight, x, dy, N, H, W, R, dil, Cout, Cin, like=None):
     torch.autograd.Variable._execution_engine.queue_callback(_join_weight_grads)
     # x and dy stay referenced until the join, so the allocator cannot hand their memory to later launches of the
     # main stream while the second stream still reads them
-    _PENDING.append((weight, dw, main, side, (x, dy)))
+    # (gradients left over from a backward pass that raised before its end-of-pass callback belong to no parameter
+    # any more: they are dropped, not added to this pass's)
+    pass_id = _backward_pass_id()
+    if _PENDING and _PENDING[0][5] != pass_id:
+        del _PENDING[:]
+    _PENDING.append((weight, dw, main, side, (x, dy), pass_id))
     return None
 
 
@@ -527,12 +540,25 @@ def interpolate_bilinear_ac(x, size):
 
 
 # ------------------------------------------------------------------- loss ----
+def _check_labels(target, K, ignore_index):
+    """config.debug_labels: labels that are neither the ignore index nor a class index raise (the reference fails
+    inside ATen for them, /root/reference/utils/loss.py:25-30; the kernels treat them as ignored)."""
+    if not config.debug_labels() or torch.cuda.is_current_stream_capturing():
+        return
+    t = target.long()
+    bad = int(((t != ignore_index) & ((t < 0) | (t >= K))).sum())
+    if bad:
+        raise ValueError("cross entropy: %d labels are neither the ignore index %d nor in [0, %d)" % (bad, ignore_index, K))
+
+
+
 class CrossEntropyFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logit, target, weight, ignore_index, size_average, batch_average):
         lg = logit if (logit.dtype == torch.float32 and logit.is_contiguous()) else logit.float().contiguous()
         tg = target if (target.dtype == torch.float32 and target.is_contiguous()) else target.float().contiguous()
         n = lg.shape[0]
+        _check_labels(tg, lg.shape[1], ignore_index)
         sums, lse = ops.ce_fwd(lg, tg, weight, ignore_index)
         pack = torch.cat([sums, torch.full((1,), float(n), dtype=torch.float32, device=lg.device)])
         parallel.all_reduce_sum_(pack)  # global {sum w*nll, sum w, batch}
@@ -566,6 +592,7 @@ class UpsampleCrossEntropyFunction(torch.autograd.Function):
         Ho, Wo = int(target.shape[-2]), int(target.shape[-1])
         v = _low_logits_pm(x)
         tg = target if (target.dtype == torch.float32 and target.is_contiguous()) else target.float().contiguous()
+        _check_labels(tg, K, ignore_index)
         sums, lse = ops.upsample_ce_fwd(v, N, Hi, Wi, tg, weight, Ho, Wo, ignore_index)
         pack = torch.cat([sums, torch.full((1,), float(N), dtype=torch.float32, device=x.device)])
         parallel.all_reduce_sum_(pack)  # global {sum w*nll, sum w, batch}
@@ -671,6 +698,8 @@ class SyncBNFunction(torch.autograd.Function):
             if gv is None or gv.dtype != xv.dtype:
                 gc = g.to(xv.dtype).contiguous(memory_format=torch.channels_last)
                 gv = pm_view_of(gc)
+            if act is not None and act.dtype == torch.uint8:
+                gv = _vector_aligned(gv)   # the bit pattern is read by the 8-channel vector kernels only
             dx = torch.empty(shape, dtype=xv.dtype, device=g.device, memory_format=torch.channels_last)
             dxv = pm_view_of(dx)
             if has_res:
@@ -692,6 +721,22 @@ class SyncBNFunction(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, dres
 
 
+def _feeder_compute_dtype(x):
+    """Operand dtype of a feeder unit: bf16 for bf16 activations and under bf16 autocast, else fp32 (an fp16
+    autocast region is not this path's: its fp32 result is what autocast's own cast policy then handles)."""
+    if x.dtype == torch.bfloat16:
+        return torch.bfloat16
+    if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        return torch.bfloat16
+    return torch.float32
+
+
+def _vector_aligned(v):
+    """The pixel-major view itself when it allows 8-channel vector access, else a contiguous copy (which does,
+    for channel counts that are multiples of 8)."""
+    return v if _pm_aligned8(v) else v.contiguous()
+
+
 # ------------------------------------------------- feeder conv + BN + ReLU ----
 class ConvBNReLUFunction(torch.autograd.Function):
     """relu(bn(conv(x))) of a feeder bottleneck block (newmodeling/backbone/resnet101_2.py:19-21 and
@@ -707,7 +752,7 @@ class ConvBNReLUFunction(torch.autograd.Function):
     def forward(ctx, x, weight, gamma, beta, conv, bn):
         N, Cin, H, W = x.shape
         R, dil = conv.kernel_size[0], conv.dilation[0]
-        cd = torch.bfloat16 if (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()) else torch.float32
+        cd = _feeder_compute_dtype(x)
         xv = _padded_input(to_pm(x, cd))
         Cout = weight.shape[0]
         M = N * H * W
@@ -750,7 +795,7 @@ class ConvBNAddReLUFunction(torch.autograd.Function):
     def forward(ctx, x, weight, gamma, beta, residual, conv, bn):
         N, Cin, H, W = x.shape
         R, dil = conv.kernel_size[0], conv.dilation[0]
-        cd = torch.bfloat16 if (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()) else torch.float32
+        cd = _feeder_compute_dtype(x)
         xv = _padded_input(to_pm(x, cd))
         rv = pm_view_of(residual)
         Cout = weight.shape[0]
@@ -784,6 +829,8 @@ class ConvBNAddReLUFunction(torch.autograd.Function):
         N, H, W = geom
         Cout, Cin = weight.shape[0], weight.shape[1]
         gv = to_pm(g, raw.dtype)
+        if act.dtype == torch.uint8:
+            gv = _vector_aligned(gv)   # the bit pattern is read by the 8-channel vector kernels only
         partials, cnt = ops.bn_bwd_stat_partials(gv, raw, coef, PM, True, act=act)
         local, dgb = ops.bn_reduce(partials, cnt, want_f32=True)
         dbeta, dgamma = dgb[0], dgb[1]

@@ -14,8 +14,9 @@ optimizer launch of ``segk.optim.SGD`` reads its hyper-parameters from device me
 PyTorch's graph-aware generator state.  Batch-norm running statistics, momentum buffers and weights are updated in
 place by the replayed kernels, so ``state_dict()`` / checkpoints see them as after eager iterations.
 
-Restrictions: the shapes of the batch are fixed at construction; one process per graph (a step that contains
-collectives is refused: recording them is not validated here, run those steps eagerly); the model must not
+Restrictions: the shapes of the batch are fixed at construction; a step whose ranks exchange through
+torch.distributed collectives is refused (run those steps eagerly) - exchanges through the mailboxes of
+segk.parallel are launches of this library and are recorded like any other; the model must not
 synchronise with the host inside the iteration (``.item()``, printing a loss) - read the returned loss tensor after
 the call instead.
 """
@@ -24,21 +25,27 @@ import torch.distributed as dist
 
 
 class GraphedTrainStep:
-    def __init__(self, model, criterion, optimizer, image, target, warmup=3, loss_fn=None):
+    def __init__(self, model, criterion, optimizer, image, target, warmup=3, loss_fn=None, buckets=None):
         """image / target: one example batch on the GPU (its values are used for the warm-up iterations).
         loss_fn(image, target) -> loss replaces ``criterion(model(image), target)`` when given (e.g.
-        ``model.forward_loss``).  `warmup` eager iterations run first; they update the weights like any iteration."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            raise RuntimeError("GraphedTrainStep: a step with collectives (world size %d) is not recorded; run it "
-                               "eagerly" % dist.get_world_size())
+        ``model.forward_loss``).  `warmup` eager iterations run first; they update the weights like any iteration.
+        buckets: the segk.parallel.GradientBuckets of a data-parallel job; the iteration then ends with
+        ``optimizer.step(flat_grads=buckets.reduce_flat())``."""
+        from . import parallel
+        if not parallel.step_is_capturable():
+            raise RuntimeError("GraphedTrainStep: a step with torch.distributed collectives (world size %d) is not "
+                               "recorded; run it eagerly, or send every exchange through the mailboxes "
+                               "(segk.parallel.connect_mailboxes(gradients=True))" % dist.get_world_size())
         if not image.is_cuda:
             raise RuntimeError("GraphedTrainStep: the batch must live on the GPU")
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
         self.loss_fn = loss_fn
+        self.buckets = buckets
         self.image = image.detach().clone()
         self.target = target.detach().clone()
         self.stream = torch.cuda.Stream(device=image.device)
         self._sync_hyper = getattr(optimizer, "sync_hyper", None)
+        self._after_replay = getattr(optimizer, "after_graph_replay", None)
         self._lr_at_record = [float(g["lr"]) for g in optimizer.param_groups]
         self.stream.wait_stream(torch.cuda.current_stream(image.device))
         with torch.cuda.stream(self.stream):
@@ -61,7 +68,10 @@ class GraphedTrainStep:
         else:
             loss = self.criterion(self.model(self.image), self.target)
         loss.backward()
-        self.optimizer.step()
+        if self.buckets is not None:
+            self.optimizer.step(flat_grads=self.buckets.reduce_flat())
+        else:
+            self.optimizer.step()
         return loss.detach()
 
     def __call__(self, image, target):
@@ -80,4 +90,6 @@ class GraphedTrainStep:
             raise RuntimeError("GraphedTrainStep: the learning rate changed, but this optimizer's recorded launch keeps "
                                "the value it was recorded with; use segk.optim.SGD")
         self.graph.replay()
+        if self._after_replay is not None:
+            self._after_replay()
         return self.loss

@@ -177,33 +177,50 @@ assert _PACK_ITEM.itemsize == 72
 
 
 class _PackEntry:
-    __slots__ = ("dst", "version", "layout")
+    __slots__ = ("dst", "version", "layout", "owner")
+
+
+class _OwnerTable:
+    """The device table of one owner's entries (an owner = one optimizer): rebuilt when their set changes."""
+    __slots__ = ("table", "blocks", "keys", "recorded")
+
+    def __init__(self):
+        self.table, self.blocks, self.keys = None, 0, None
+        self.recorded = None   # keys of the table a recorded HIP graph replays, once there is one
 
 
 class _WeightPackCache:
     def __init__(self):
-        self.params = {}     # data_ptr -> weakref of the registered parameter
+        self.params = {}     # data_ptr -> (weakref of the registered parameter, owner id)
         self.entries = {}    # (data_ptr, packed dtype, transpose) -> _PackEntry
-        self.table = None    # StagedTable of the entries, rebuilt when their set changes
-        self.blocks = 0
-        self.keys = None
+        self.tables = {}     # owner id -> _OwnerTable
 
-    def register(self, params):
+    def register(self, params, owner):
         for p in params:
             if isinstance(p, torch.Tensor) and p.is_cuda and p.dim() == 4 and p.shape[2] == p.shape[3] \
                     and p.shape[2] in (1, 3):
-                self.params[p.data_ptr()] = weakref.ref(p)
+                old = self.params.get(p.data_ptr())
+                if old is not None and old[0]() is not p:
+                    # the allocator handed a freed weight's address to this one: what was kept for the old weight
+                    # (operands, owner) says nothing about the new
+                    for k in [k for k in self.entries if k[0] == p.data_ptr()]:
+                        del self.entries[k]
+                self.params[p.data_ptr()] = (weakref.ref(p), owner)
 
     def owner(self, w):
-        ref = self.params.get(w.data_ptr())
-        p = ref() if ref is not None else None
+        rec = self.params.get(w.data_ptr())
+        p = rec[0]() if rec is not None else None
         if p is None or p.data_ptr() != w.data_ptr() or p.shape != w.shape or p.stride() != w.stride() \
                 or p.dtype != w.dtype:
-            return None
-        return p
+            return None, None
+        return p, rec[1]
+
+    def param(self, key):
+        rec = self.params.get(key[0])
+        return rec[0]() if rec is not None else None
 
     def sweep(self):
-        dead = [k for k, ref in self.params.items() if ref() is None or ref().data_ptr() != k]
+        dead = [k for k, (ref, _) in self.params.items() if ref() is None or ref().data_ptr() != k]
         for k in dead:
             del self.params[k]
         gone = [k for k in self.entries if k[0] not in self.params]
@@ -213,11 +230,17 @@ class _WeightPackCache:
 
 
 _PACKS = _WeightPackCache()
+_SHARED_OWNER = 0
+# Tables (and the tensors their rows point at) that a recorded HIP graph replays: the graph holds raw device
+# addresses, so none of this may ever return to the allocator while the process lives.
+_RECORDED_KEEP = []
 
 
-def cache_weight_packs(params):
-    """Keep the packed operands of these convolution weights between uses (see repack_cached_weights)."""
-    _PACKS.register(params)
+def cache_weight_packs(params, owner=None):
+    """Keep the packed operands of these convolution weights between uses (see repack_cached_weights).  `owner`
+    (any object, e.g. the optimizer that updates them) groups the weights that one repack_cached_weights(owner)
+    call renews; weights registered without one share a group."""
+    _PACKS.register(params, id(owner) if owner is not None else _SHARED_OWNER)
 
 
 def invalidate_weight_packs():
@@ -227,37 +250,74 @@ def invalidate_weight_packs():
         e.version = -1
 
 
-def repack_cached_weights():
-    """Renew every kept packed operand from its weight in one launch (segk_pack_weights).  For callers that change
-    registered weights without torch noticing (segk.optim.SGD's kernels write through raw pointers)."""
-    c = _PACKS
-    if not c.entries:
+def invalidate_unrecorded_packs(owner=None):
+    """After the replay of a HIP graph that contains repack_cached_weights(owner): kept operands of that owner that
+    the recorded table does not renew (created after the recording) no longer match their weights."""
+    oid = id(owner) if owner is not None else _SHARED_OWNER
+    t = _PACKS.tables.get(oid)
+    if t is None or t.recorded is None:
         return
+    for k, e in _PACKS.entries.items():
+        if e.owner == oid and k not in t.recorded:
+            e.version = -1
+
+
+def repack_cached_weights(owner=None):
+    """Renew every kept packed operand of `owner`'s weights in one launch (segk_pack_weights).  For callers that
+    change registered weights without torch noticing (segk.optim.SGD's kernels write through raw pointers).
+    Recorded into a HIP graph, the launch keeps reading the device table it was recorded with: that table, the
+    weights and the operands it names stay allocated for the life of the process, and a table is never built
+    during a capture (run one step eagerly first)."""
+    c = _PACKS
+    oid = id(owner) if owner is not None else _SHARED_OWNER
     capturing = torch.cuda.is_current_stream_capturing()
-    if not capturing and c.sweep():
-        c.keys = None
-        if not c.entries:
-            return
-    keys = tuple(c.entries)
-    if c.keys != keys:
+    if not capturing:
+        c.sweep()
+    keys = tuple(k for k, e in c.entries.items() if e.owner == oid)
+    if not keys:
+        return
+    t = c.tables.get(oid)
+    if t is None:
+        t = c.tables[oid] = _OwnerTable()
+    if t.keys != keys:
+        if capturing:
+            raise RuntimeError("segk.ops.repack_cached_weights: the set of kept weight operands changed since the "
+                               "last eager step; run one step eagerly before recording a HIP graph")
         rows = np.zeros(len(keys), dtype=_PACK_ITEM)
         first = 0
         for i, k in enumerate(keys):
             e = c.entries[k]
-            p = c.params[k[0]]()
+            p = c.param(k)
             Cout, Cin, R, s_co, s_ci, s_tap = e.layout
             rows[i] = (p.data_ptr(), e.dst.data_ptr(), s_co, s_ci, s_tap, _dt(p), _dt(e.dst), Cout, Cin, R,
                        1 if k[2] else 0, first, 0)
             first += call("segk_pack_weight_blocks", Cout, Cin, R, s_tap, 1 if k[2] else 0)
-        c.table = StagedTable(rows, c.entries[keys[0]].dst.device)
-        c.table.upload()
-        c.blocks, c.keys = first, keys
+        # (a table that a graph replays is left alone: the new set gets a table of its own)
+        t.table = StagedTable(rows, c.entries[keys[0]].dst.device)
+        t.table.upload()
+        t.blocks, t.keys = first, keys
+    if capturing:
+        _RECORDED_KEEP.append((t.table, [c.param(k) for k in keys], [c.entries[k].dst for k in keys]))
+        t.recorded = frozenset(keys)
     t0 = _hbm_start()
-    call("segk_pack_weights", ctypes.c_void_p(c.table.ptr()), len(keys), c.blocks, _stream())
+    call("segk_pack_weights", ctypes.c_void_p(t.table.ptr()), len(keys), t.blocks, _stream())
     if t0 is not None:
-        _hbm_stop("pack_weight", sum(_nbytes(c.params[k[0]](), c.entries[k].dst) for k in keys), t0)
+        _hbm_stop("pack_weight", sum(_nbytes(c.param(k), c.entries[k].dst) for k in keys), t0)
     for k in keys:
-        c.entries[k].version = c.params[k[0]]()._version
+        c.entries[k].version = c.param(k)._version
+
+
+# Debug switch (segk.config.set_debug_packs): every use of a kept operand packs the weight again and compares.
+def _check_kept_pack(w, entry, dtype, transpose):
+    fresh = torch.empty_like(entry.dst)
+    s_co, s_ci, s_tap = _weight_strides(w)
+    Cout, Cin, R, _ = w.shape
+    call("segk_pack_weight_strided", _ptr(w), _dt(w), s_co, s_ci, s_tap, _ptr(fresh), _dt(fresh), Cout, Cin, R,
+         1 if transpose else 0, _stream())
+    if not torch.equal(fresh.view(torch.uint8), entry.dst.view(torch.uint8)):
+        raise RuntimeError("segk: the kept packed operand of a %s weight no longer matches the weight (it was changed "
+                           "in place through .data?); call segk.ops.invalidate_weight_packs() after such a change"
+                           % (tuple(w.shape),))
 
 
 def pack_weight(w, dtype, transpose=False, out=None):
@@ -272,16 +332,23 @@ def pack_weight(w, dtype, transpose=False, out=None):
     dense = w.is_contiguous() or w.is_contiguous(memory_format=torch.channels_last)
     entry = None
     if out is None and dense and _PACKS.params:
-        owner = _PACKS.owner(w)
+        owner, oid = _PACKS.owner(w)
         if owner is not None:
             key = (w.data_ptr(), dtype, bool(transpose))
             entry = _PACKS.entries.get(key)
+            if entry is not None and entry.owner != oid:
+                del _PACKS.entries[key]        # kept for another weight that once lived at this address
+                entry = None
             if entry is not None and entry.version == owner._version:
+                from . import config
+                if config.debug_packs() and not torch.cuda.is_current_stream_capturing():
+                    _check_kept_pack(w, entry, dtype, transpose)
                 return entry.dst
             # (no new entry while a graph is recorded: a kept operand must not live in the graph's memory pool)
             if entry is None and not torch.cuda.is_current_stream_capturing():
                 entry = _PACKS.entries[key] = _PackEntry()
                 entry.dst = None
+                entry.owner = oid
             if entry is not None:
                 entry.version = owner._version
     if not dense:

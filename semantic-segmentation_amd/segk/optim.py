@@ -87,6 +87,7 @@ class SGD(torch.optim.Optimizer):
         low = {id(p) for p in low_precision}
         self._groups = None
         self._groups_src = None
+        self._recorded_groups = []   # chunk tables a recorded HIP graph replays: never freed while this object lives
         self._hyper_dev = None    # [groups, 4] fp32 on the device, read by recorded steps
         self._hyper_host = None   # pinned ring of the same shape
         self._hyper_turn = 0
@@ -110,7 +111,7 @@ class SGD(torch.optim.Optimizer):
                 st["momentum_buffer"] = torch.zeros(p.numel(), dtype=torch.float32, device=p.device)
         # convolution weights keep their packed operands between uses; step() renews them in one launch
         from . import ops
-        ops.cache_weight_packs([p for g in self.param_groups for p in g["params"]])
+        ops.cache_weight_packs([p for g in self.param_groups for p in g["params"]], owner=self)
 
     @torch.no_grad()
     def step(self, closure=None, flat_grads=None):
@@ -123,6 +124,8 @@ class SGD(torch.optim.Optimizer):
         if self._groups is None or self._groups_src is not flat_grads:
             self._groups = [_Group(g["params"], self.state, flat_grads) for g in self.param_groups if g["params"]]
             self._groups_src = flat_grads
+        if recording and not any(g is self._groups for g in self._recorded_groups):
+            self._recorded_groups.append(self._groups)   # the graph holds these tables' device addresses
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         live_groups = [g for g in self.param_groups if g["params"]]
         for k, (grp, hp) in enumerate(zip(self._groups, live_groups)):
@@ -137,8 +140,14 @@ class SGD(torch.optim.Optimizer):
                      float(hp["weight_decay"]), stream)
         # the kernels above wrote the weights through raw pointers: torch's version counters did not move
         from . import ops
-        ops.repack_cached_weights()
+        ops.repack_cached_weights(owner=self)
         return loss
+
+    def after_graph_replay(self):
+        """For whoever replays a HIP graph that contains step(): kept weight operands the recorded launch does not
+        renew are marked stale."""
+        from . import ops
+        ops.invalidate_unrecorded_packs(owner=self)
 
     def sync_hyper(self):
         """Write lr / momentum / weight decay of every (non-empty) parameter group to the device table that recorded
@@ -187,8 +196,14 @@ class SGD(torch.optim.Optimizer):
         """Copies the saved values INTO the existing fp32 state tensors (their addresses are in the kernels' tables
         and, for fp32 parameters, the master is the parameter itself), whatever dtype or device they were saved
         with.  A parameter without a saved entry gets a zero momentum buffer (= torch's 'no buffer yet').  A
-        bf16-held parameter takes its master from the checkpoint when it has one, otherwise from the parameter's
-        current value (load the weights first; `load_full_precision_state_dict` restores exact masters)."""
+        bf16-held parameter takes its master from the checkpoint when it has one; without one (a torch.optim.SGD
+        checkpoint) the existing master stays when the parameter still equals its bf16 rounding
+        (`load_full_precision_state_dict` restored it exactly) and is re-derived from the parameter otherwise (the
+        weights were loaded into the model after the master was last set)."""
+        for hook in self._optimizer_load_state_dict_pre_hooks.values():
+            changed = hook(self, state_dict)
+            if changed is not None:
+                state_dict = changed
         groups = state_dict["param_groups"]
         saved = state_dict["state"]
         if len(groups) != len(self.param_groups):
@@ -218,13 +233,19 @@ class SGD(torch.optim.Optimizer):
                     master = self._shaped(st["master"], p)
                     if entry and entry.get("master") is not None:
                         master.copy_(entry["master"].reshape(p.shape))
-                    else:
+                    elif not torch.equal(master.to(torch.bfloat16), p.data):
+                        # no master in the checkpoint (one written by torch.optim.SGD) and the bf16 copy is not the
+                        # rounded master any more: the weights were loaded into the parameter, they are what counts.
+                        # A master that still rounds to the parameter (load_full_precision_state_dict restored it
+                        # exactly) is left alone.
                         master.copy_(p.data)
                     p.data.copy_(master)
-        self._groups = None   # rebuild the chunk tables on the next step
+        self._groups = None   # rebuild the chunk tables on the next step (tables of a recorded step stay alive)
         self._groups_src = None
         from . import ops
         ops.invalidate_weight_packs()   # p.data.copy_ above moved no version counter
+        for hook in self._optimizer_load_state_dict_post_hooks.values():
+            hook(self)
 
     @torch.no_grad()
     def load_full_precision_state_dict(self, model, state_dict, strict=True):

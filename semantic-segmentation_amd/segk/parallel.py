@@ -9,6 +9,10 @@ running the whole batch:
   1. SyncBN forward/backward: all-reduce(SUM) of a [2C+1] fp64 vector per layer;
   2. loss: all-reduce(SUM) of [sum w*nll, sum w, batch] so each rank divides by the global normaliser;
   3. gradients: bucketed all-reduce(SUM) (each rank already divided by the global normaliser).
+The small exchanges (1, 2 and the evaluator's matrix) take the latency path when it is available: one-shot
+all-reduces through peer-mapped mailboxes (connect_mailboxes, csrc/comm.hip), launches of this library on the
+compute stream that a HIP graph can record.  config.sync_exchange: "auto" (default: mailboxes when they connect and
+pass their self-test, else torch.distributed), "mailbox" (required), "dist" (never).
 """
 import os
 
@@ -42,7 +46,163 @@ def init_from_env(backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group(backend=backend)
+    from . import config
+    mode = config.sync_exchange()
+    if mode != "dist" and torch.cuda.is_available():
+        # (the device this rank computes on must be current: the mailbox is allocated there)
+        if backend != "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+        ok = connect_mailboxes()
+        if mode == "mailbox" and not ok:
+            raise RuntimeError("SEGK_SYNC_EXCHANGE=mailbox, but the mailbox path is not available: %s" % _MAILBOX["why"])
     return dist.get_rank(), dist.get_world_size()
+
+
+# ---- the latency path: one-shot all-reduce through peer-mapped mailboxes (csrc/comm.hip) -------------------------
+_MAILBOX = {"on": False, "grads": False, "why": "not tried"}
+
+
+def mailbox_active():
+    return _MAILBOX["on"]
+
+
+def exchange_description():
+    """What carries the small exchanges of this job (for logs and the benchmark line)."""
+    if not is_distributed():
+        return None
+    if _MAILBOX["on"]:
+        return "peer-mapped mailboxes (segk_mailbox_allreduce), gradients: %s" % (
+            "mailboxes" if _MAILBOX["grads"] else dist.get_backend())
+    return "torch.distributed %s (mailboxes: %s)" % (dist.get_backend(), _MAILBOX["why"])
+
+
+def connect_mailboxes(timeout_ms=0, self_test=True, gradients=None):
+    """Create this rank's mailbox, exchange the IPC handles through torch.distributed, map the peers' mailboxes and
+    (self_test) run a few exchanges of known vectors whose sums every rank checks bit for bit.  Returns whether the
+    mailbox path is in use afterwards; any failure leaves the job on torch.distributed's collectives and says why
+    in exchange_description().  gradients=True also sends the gradient buckets through the mailboxes (in chunks: a
+    rehearsal path for ranks that share one device, where RCCL cannot run)."""
+    import ctypes
+
+    from . import _lib
+    if not is_distributed() or not torch.cuda.is_available():
+        _MAILBOX["why"] = "one rank or no GPU"
+        return False
+    if _MAILBOX["on"]:
+        return True
+    world, me = dist.get_world_size(), dist.get_rank()
+    ok, why = True, ""
+    handle = ctypes.create_string_buffer(64)
+    try:
+        _lib.call("segk_mailbox_create", world, handle)
+    except _lib.SegkError as e:
+        ok, why = False, str(e)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (ok, handle.raw))
+    if not all(g[0] for g in gathered):
+        _MAILBOX["why"] = why or "another rank could not create its mailbox"
+        if ok:
+            _lib.call("segk_mailbox_destroy")
+        return False
+    try:
+        _lib.call("segk_mailbox_connect", me, world, ctypes.c_char_p(b"".join(g[1] for g in gathered)), int(timeout_ms))
+    except _lib.SegkError as e:
+        ok, why = False, str(e)
+    flags = [None] * world
+    dist.all_gather_object(flags, ok)
+    if not all(flags):
+        _MAILBOX["why"] = why or "another rank could not map the mailboxes"
+        return False
+    _MAILBOX["on"] = True
+    if self_test:
+        good = _mailbox_self_test(me, world)
+        flags = [None] * world
+        dist.all_gather_object(flags, good)
+        if not all(flags):
+            _MAILBOX["on"] = False
+            _MAILBOX["why"] = "self-test failed on rank(s) %s" % [i for i, f in enumerate(flags) if not f]
+            return False
+    if gradients is None:
+        gradients = os.environ.get("SEGK_GRAD_EXCHANGE", "") == "mailbox"
+    _MAILBOX["grads"] = bool(gradients)
+    _MAILBOX["why"] = "connected"
+    return True
+
+
+def _mailbox_self_test(me, world, rounds=6):
+    """Exchanges of vectors every rank can predict (integers, exact in fp64 / fp32), of the lengths the batch norms
+    use and one that needs several chunks; False when a sum is wrong or a wait timed out."""
+    import ctypes
+
+    from . import _lib
+    dev = torch.device("cuda", torch.cuda.current_device())
+    try:
+        for k, n in enumerate([1, 97, 513, 4097, 3, 10000][:rounds]):
+            base = torch.arange(n, dtype=torch.float64, device=dev) % 1021 + k
+            mine = base * (me + 1)
+            want = base * (world * (world + 1) // 2)
+            if k % 2:
+                mine, want = mine.float(), want.float()
+            all_reduce_sum_(mine)
+            if not torch.equal(mine, want):
+                return False
+        return _lib.call("segk_mailbox_status") >= 0
+    except _lib.SegkError:
+        return False
+
+
+def check_exchange():
+    """Synchronous: raises when an in-kernel wait of the mailbox path ran out of time (a rank is gone, or the ranks
+    issued different sequences of exchanges).  Returns the number of exchanges completed on this rank."""
+    from . import _lib
+    return _lib.call("segk_mailbox_status") if _MAILBOX["on"] else 0
+
+
+def step_is_capturable():
+    """Whether every exchange of a training step can be recorded in a HIP graph: true when batch-norm statistics,
+    loss sums and gradient buckets all travel through the mailboxes (launches of this library on the capturing
+    stream); torch.distributed's collectives are left out of graphs here."""
+    return not is_distributed() or (_MAILBOX["on"] and _MAILBOX["grads"])
+
+
+def _mailbox_all_reduce(t):
+    import ctypes
+
+    from . import _lib
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if t.dtype in (torch.float64, torch.float32) and t.is_contiguous():
+        name = "segk_mailbox_allreduce_f64" if t.dtype == torch.float64 else "segk_mailbox_allreduce_f32"
+        _lib.call(name, ctypes.c_void_p(t.data_ptr()), t.numel(), stream)
+        return t
+    if t.dtype == torch.int64:
+        # counts (the confusion matrix): exact in fp64 up to 2^53
+        w = t.to(torch.float64).contiguous()
+        _lib.call("segk_mailbox_allreduce_f64", ctypes.c_void_p(w.data_ptr()), w.numel(), stream)
+        t.copy_(w.to(torch.int64))
+        return t
+    w = t.to(torch.float64).contiguous()
+    _lib.call("segk_mailbox_allreduce_f64", ctypes.c_void_p(w.data_ptr()), w.numel(), stream)
+    t.copy_(w)
+    return t
+
+
+def assert_same_on_all_ranks(t, what):
+    """Debug check (config.set_debug_sync_stats): gathers the tensor from every rank and compares bit for bit; ranks
+    that hold different values raise.  Synchronises with the host."""
+    if not is_distributed():
+        return
+    mine = t.detach().to("cpu", torch.float64).contiguous()
+    got = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    if dist.get_backend() == "gloo":
+        dist.all_gather(got, mine)
+    else:
+        dev = [torch.empty_like(t, dtype=torch.float64) for _ in got]
+        dist.all_gather(dev, t.detach().to(torch.float64).contiguous())
+        got = [d.cpu() for d in dev]
+    bad = [r for r, g in enumerate(got) if not torch.equal(g.view(torch.int64), got[0].view(torch.int64))]
+    if bad:
+        raise RuntimeError("%s differ between ranks: rank(s) %s do not hold rank 0's values (rank %d reporting)"
+                           % (what, bad, dist.get_rank()))
 
 
 def _host_staged(t):
@@ -54,7 +214,9 @@ def _host_staged(t):
 def all_reduce_sum_(t):
     """In-place SUM all-reduce on the current stream; identity on one rank."""
     if is_distributed():
-        if _host_staged(t):
+        if _MAILBOX["on"] and t.is_cuda:
+            _mailbox_all_reduce(t)
+        elif _host_staged(t):
             h = t.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM)
             t.copy_(h)
@@ -176,6 +338,9 @@ class GradientBuckets:
                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         if not is_distributed():
             self._works[k] = None
+        elif _MAILBOX["on"] and _MAILBOX["grads"]:
+            _mailbox_all_reduce(flat)
+            self._works[k] = None
         elif _host_staged(flat):
             all_reduce_sum_(flat)
             self._works[k] = None
@@ -228,8 +393,8 @@ class GradientBuckets:
                 else:
                     flat[off:off + n].copy_(p.grad.reshape(-1))
                 off += n
-            if _host_staged(flat):
-                all_reduce_sum_(flat)
+            if (_MAILBOX["on"] and _MAILBOX["grads"]) or _host_staged(flat):
+                all_reduce_sum_(flat) if not _MAILBOX["on"] else _mailbox_all_reduce(flat)
                 works.append(None)
             else:
                 works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))

@@ -5,6 +5,8 @@ MODE cpu : gloo on CPU tensors - the three exchanges of segk.parallel (BN statis
 MODE gpu : gloo on CUDA tensors, every rank on cuda:0 (one-GPU box) - the real HIP modules with
            SynchronizedBatchNorm2d in feeder and head, head-only model to keep it quick.
 MODE nccl: the same with rank r on cuda:r over RCCL (needs WORLD devices).
+MODE mbx : every rank on cuda:0 again, gloo only for the set-up: all exchanges through the peer-mapped mailboxes
+           (segk_mailbox_allreduce), and SGD iterations replayed from one HIP graph per rank.
 Each rank writes OUTDIR/rank{R}.npz; the parent compares with a single process that ran the whole batch.
 """
 import os
@@ -96,11 +98,10 @@ def run_cpu(rank, world, outdir):
 GPU_N, GPU_K = 4, 7
 
 
-def gpu_case(device, images, sync, overlap_buckets=None, backwards=1):
+def make_net(device):
     """Head + a small SyncBN'd stem standing in for the feeder (a strided convolution, then a dilated 3x3
     convolution -> batch norm -> ReLU unit on the implicit-GEMM kernels, whose statistics come out of the
-    convolution's epilogue and are all-reduced like any other), one SGD-free step; returns loss, grads.
-    overlap_buckets (MB): attach GradientBuckets(overlap=True) before backward and finish them (net.overlapped)."""
+    convolution's epilogue and are all-reduced like any other)."""
     from segk.modeling.aspp import build_aspp
     from segk.modeling.decoder import build_decoder
     from segk.modeling.sync_batchnorm import SynchronizedBatchNorm2d
@@ -132,12 +133,23 @@ def gpu_case(device, images, sync, overlap_buckets=None, backwards=1):
 
     net = cases._load(Net(), SEED, "gpudist", device)
     cases._zero_dropout(net)
-    net.train()
+    return net.train()
+
+
+def shard_inputs(device, images, tag="gd"):
     lo, hi = images
-    img = torch.from_numpy(gen.normal(SEED, "gd/img", (GPU_N, 3, 41, 37)) * cases._gain(GPU_N))[lo:hi].to(device)
-    tgt = torch.from_numpy(gen.labels(SEED, "gd/lab", (GPU_N, 41, 37), GPU_K, border=1, ignore_frac=0.2))
+    img = torch.from_numpy(gen.normal(SEED, tag + "/img", (GPU_N, 3, 41, 37)) * cases._gain(GPU_N))[lo:hi].to(device)
+    tgt = torch.from_numpy(gen.labels(SEED, tag + "/lab", (GPU_N, 41, 37), GPU_K, border=1, ignore_frac=0.2))
     tgt[0, :30] = 255
-    tgt = tgt[lo:hi].to(device)
+    return img, tgt[lo:hi].to(device)
+
+
+def gpu_case(device, images, sync, overlap_buckets=None, backwards=1):
+    """One SGD-free step of make_net on a shard of the batch; returns net, loss, output.
+    overlap_buckets (MB): attach GradientBuckets(overlap=True) before backward and finish them (net.overlapped)."""
+    from segk.utils.loss import SegmentationLosses
+    net = make_net(device)
+    img, tgt = shard_inputs(device, images)
     if overlap_buckets is not None:
         from segk import parallel
         net.overlapped = parallel.GradientBuckets(list(net.parameters()), bucket_mb=overlap_buckets, overlap=True)
@@ -177,11 +189,71 @@ def run_gpu(rank, world, outdir, device="cuda:0"):
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), **res)
 
 
+def train_steps(device, images, steps, graphed):
+    """`steps` SGD iterations of make_net on a shard (segk.optim.SGD reading the all-reduced flat buckets), issued
+    launch by launch or - after two eager warm-up iterations - replayed from one HIP graph per rank.  Returns the
+    losses and the final weights."""
+    from segk import parallel
+    from segk.graph import GraphedTrainStep
+    from segk.optim import SGD
+    from segk.utils.loss import SegmentationLosses
+    net = make_net(device)
+    opt = SGD(net.parameters(), lr=0.02, momentum=0.9, weight_decay=5e-4)
+    crit = SegmentationLosses(cuda=True).build_loss("ce")
+    buckets = parallel.GradientBuckets(list(net.parameters()), bucket_mb=0.5)
+    batches = [shard_inputs(device, images, "gd%d" % (i % 2)) for i in range(steps)]
+    losses = []
+    if graphed:
+        stepper = GraphedTrainStep(net, crit, opt, batches[0][0], batches[0][1], warmup=2, buckets=buckets)
+        for img, tgt in batches[2:]:
+            losses.append(float(stepper(img, tgt)))
+    else:
+        for i, (img, tgt) in enumerate(batches):
+            k = 0 if i < 2 else i   # the recorded trainer warms up twice on its example batch
+            opt.zero_grad(set_to_none=True)
+            loss = crit(net(batches[k][0]), batches[k][1])
+            loss.backward()
+            opt.step(flat_grads=buckets.reduce_flat())
+            if i >= 2:
+                losses.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    return losses, {n: p.detach().float().cpu().numpy() for n, p in net.named_parameters()}
+
+
+def run_mailbox(rank, world, outdir):
+    """Every exchange through the peer-mapped mailboxes: the case of run_gpu (one step, statistics + loss sums +
+    gradient buckets), then five SGD iterations issued eagerly and the same five with the last three replayed from
+    a HIP graph, with the cross-rank comparison of the statistics switched on for the eager ones."""
+    from segk import config, parallel
+    if world > 1:
+        assert parallel.connect_mailboxes(timeout_ms=20000, gradients=True), parallel.exchange_description()
+        assert parallel.step_is_capturable()
+    run_gpu(rank, world, outdir)
+    res = dict(np.load(os.path.join(outdir, "rank%d.npz" % rank)))
+    per = GPU_N // world
+    shard_ = (rank * per, (rank + 1) * per)
+    # (MIOpen's default convolution gradients of the two stand-in feeder layers differ from run to run; its
+    # deterministic choices make the eager and the replayed run comparable)
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    config.set_debug_sync_stats(True)
+    eager_losses, eager_w = train_steps("cuda:0", shard_, 5, graphed=False)
+    config.set_debug_sync_stats(False)
+    graph_losses, graph_w = train_steps("cuda:0", shard_, 5, graphed=True)
+    torch.use_deterministic_algorithms(False)
+    res["eager_losses"], res["graph_losses"] = np.array(eager_losses), np.array(graph_losses)
+    for n, v in eager_w.items():
+        res["we/" + n] = v
+    for n, v in graph_w.items():
+        res["wg/" + n] = v
+    res["exchanges"] = np.array([parallel.check_exchange()])
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), **res)
+
+
 def main():
     mode, rank, world, port, outdir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import faulthandler
-    faulthandler.dump_traceback_later(60, exit=True)  # a stuck collective names its call site instead of hanging the test
+    faulthandler.dump_traceback_later(180 if mode == "mbx" else 60, exit=True)  # a stuck collective names its call site instead of hanging the test
     if mode == "nccl":   # one rank per device over RCCL, the production transport
         torch.cuda.set_device(rank)
     if world > 1:
@@ -192,6 +264,9 @@ def main():
         run_cpu(rank, world, outdir)
     elif mode == "nccl":
         run_gpu(rank, world, outdir, device="cuda:%d" % rank)
+    elif mode == "mbx":
+        torch.cuda.set_device(0)
+        run_mailbox(rank, world, outdir)
     else:
         torch.cuda.set_device(0)
         run_gpu(rank, world, outdir)

@@ -196,3 +196,29 @@ def test_pack_weight_layouts_agree():
     w1 = torch.from_numpy(gen.normal(SEED, "pw/w1", (48, 256, 1, 1))).to(dev)
     p1 = ops.pack_weight(w1, torch.float32)
     assert torch.equal(p1[0], w1.reshape(48, 256))
+
+
+def test_unit_1x1_residual_backward_takes_unaligned_gradients():
+    """The residual unit keeps one bit per element for its ReLU, which the backward kernels read eight channels at a
+    time; a gradient that arrives as a channel slice of a wider tensor (row stride not the channel count, base not
+    16-byte aligned) is copied into an aligned buffer first instead of being refused."""
+    from segk.modeling.sync_batchnorm import SynchronizedBatchNorm2d
+    dev, Cin, Cout, n, h, w = "cuda", 256, 1024, 2, 5, 7
+    torch.manual_seed(2)
+    conv = nn.Conv2d(Cin, Cout, 1, bias=False).to(dev).to(memory_format=torch.channels_last)
+    conv.weight.data = conv.weight.data.to(torch.bfloat16)
+    cl = lambda t: t.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    x, res = cl(torch.randn(n, Cin, h, w).relu()), cl(torch.randn(n, Cout, h, w).relu())
+    wide = cl(torch.randn(n, Cout + 4, h, w))
+    grads = {}
+    for name, gy in (("aligned", wide[:, 4:].contiguous(memory_format=torch.channels_last)), ("slice", wide[:, 4:])):
+        bn = SynchronizedBatchNorm2d(Cout).to(dev)
+        xd, rd = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        conv.weight.grad = None
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            y = bn.forward_conv_add_relu(conv, xd, rd)
+        y.backward(gy)
+        grads[name] = [xd.grad.clone(), rd.grad.clone(), conv.weight.grad.clone(), bn.weight.grad.clone()]
+    assert wide[:, 4:].data_ptr() % 16 != 0
+    for a, b in zip(grads["aligned"], grads["slice"]):
+        assert torch.equal(a, b)

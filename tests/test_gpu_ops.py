@@ -602,3 +602,26 @@ def test_bn_residual_relu_fused(ops, dtype, tol):
     dx2, dres2 = torch.empty_like(x), torch.empty_like(x)
     ops.bn_bwd_apply(g, x, dx2, coef, sums2, PM, True, act=bits, dres=dres2)
     assert torch.equal(sums2, sums) and torch.equal(dx2, dx) and torch.equal(dres2, dres)
+
+
+def test_debug_labels_raises_on_out_of_range_labels():
+    """config.set_debug_labels: a label that is neither the ignore index nor a class raises, like the reference's
+    nn.CrossEntropyLoss does (/root/reference/utils/loss.py:25-30); without the switch the kernels ignore it."""
+    from segk import config
+    from segk.utils.loss import SegmentationLosses
+    K = 5
+    logit = torch.randn(2, K, 6, 7, device="cuda")
+    target = torch.randint(0, K, (2, 6, 7), device="cuda").float()
+    target[0, 0, 0] = 255.0
+    crit = SegmentationLosses(cuda=True).build_loss("ce")
+    clean = float(crit(logit, target))
+    bad = target.clone()
+    bad[1, 2, 3] = float(K + 1)
+    assert np.isfinite(float(crit(logit, bad)))      # ignored silently by default
+    config.set_debug_labels(True)
+    try:
+        assert float(crit(logit, target)) == clean
+        with pytest.raises(ValueError, match="neither the ignore index"):
+            crit(logit, bad)
+    finally:
+        config.set_debug_labels(False)

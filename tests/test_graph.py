@@ -95,7 +95,9 @@ def deterministic_feeder():
     torch.use_deterministic_algorithms(False)
 
 
-def test_replayed_iterations_equal_eager_iterations(deterministic_feeder):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_replayed_iterations_equal_eager_iterations(deterministic_feeder, overlap):
+    """overlap: weight gradients on the second stream inside the recorded iteration (what bench.py runs)."""
     from segk import config
     from segk.graph import GraphedTrainStep
     dev = "cuda:0"
@@ -125,7 +127,8 @@ def test_replayed_iterations_equal_eager_iterations(deterministic_feeder):
 
         opt2, crit2, sched2 = _trainer(replayed)
         sched2(opt2, 0, 0, 0.0)
-        stepper = GraphedTrainStep(replayed, crit2, opt2, images[0], targets[0], warmup=2)
+        with config.overlap_wgrad_as(overlap):
+            stepper = GraphedTrainStep(replayed, crit2, opt2, images[0], targets[0], warmup=2)
         got = []
         for i in range(2, 6):
             sched2(opt2, i, 0, 0.0)
@@ -184,3 +187,54 @@ def test_weight_gradients_on_second_stream_equal_inline(deterministic_feeder):
     assert inline.keys() == overlapped.keys()
     for n in inline:
         assert torch.equal(inline[n], overlapped[n]), n
+
+
+def test_recorded_step_survives_another_optimizer(deterministic_feeder):
+    """A recorded iteration holds raw device addresses of the optimizer's chunk tables and of the table that renews
+    the kept weight operands.  A second model with its own segk.optim.SGD, created, stepped and destroyed between
+    replays - which changes the process-wide set of kept operands - and a load_state_dict on the recorded optimizer
+    must not disturb the replays: losses equal the eagerly issued twin's."""
+    import gc
+
+    from segk import config, ops
+    from segk.graph import GraphedTrainStep
+    dev = "cuda:0"
+    config.set_compute_dtype(torch.float32)
+    g = torch.Generator().manual_seed(5)
+    images = [torch.randn(2, 3, 65, 65, generator=g).to(dev) for _ in range(5)]
+    targets = [torch.randint(0, 6, (2, 65, 65), generator=g).float().to(dev) for _ in range(5)]
+
+    with config.feeder_conv_as("torch"):
+        eager = _small_model(13)
+        replayed = copy.deepcopy(eager)
+        opt, crit, _ = _trainer(eager)
+        want = []
+        for i in range(5):
+            k = 0 if i < 2 else i
+            opt.zero_grad(set_to_none=True)
+            loss = crit(eager(images[k]), targets[k])
+            loss.backward()
+            opt.step()
+            want.append(float(loss.detach()))
+
+        opt2, crit2, _ = _trainer(replayed)
+        stepper = GraphedTrainStep(replayed, crit2, opt2, images[0], targets[0], warmup=2)
+        got = [float(stepper(images[2], targets[2]))]
+        # another model + optimizer: registers weights, creates kept operands, steps eagerly, dies
+        other = _small_model(17)
+        opt3, crit3, _ = _trainer(other)
+        for _ in range(2):
+            opt3.zero_grad(set_to_none=True)
+            crit3(other(images[1]), targets[1]).backward()
+            opt3.step()
+        del other, opt3, crit3
+        gc.collect()
+        torch.cuda.empty_cache()
+        junk = [torch.full((1 << 20,), float("nan"), device=dev) for _ in range(64)]   # reuse whatever was freed
+        got.append(float(stepper(images[3], targets[3])))
+        # the recorded optimizer reloads its own state: its tables are rebuilt for eager use, the graph keeps the old ones
+        opt2.load_state_dict(opt2.state_dict())
+        got.append(float(stepper(images[4], targets[4])))
+        del junk
+    assert np.allclose(got, want[2:], rtol=1e-5), (got, want[2:])
+    assert len(ops._RECORDED_KEEP) >= 1

@@ -286,3 +286,64 @@ def test_kept_weight_packs_follow_the_optimizer():
     ops.invalidate_weight_packs()
     got = ops.pack_weight(ps[1].detach(), torch.float32, transpose=True)
     assert torch.equal(got, ops.pack_weight(ps[1].detach().clone(), torch.float32, transpose=True))
+
+
+@pytest.mark.gpu
+def test_debug_packs_catches_a_weight_changed_through_data():
+    """config.set_debug_packs: a registered weight written through `.data` (no version counter moves) is caught at
+    the next use of its kept operand instead of multiplying with stale values."""
+    from segk import config, ops
+    from segk.optim import SGD
+    dev = "cuda"
+    p = torch.nn.Parameter(torch.randn(32, 64, 3, 3, device=dev))
+    opt = SGD([p], lr=0.1)
+    kept = ops.pack_weight(p.detach(), torch.bfloat16)
+    assert ops.pack_weight(p.detach(), torch.bfloat16) is kept
+    p.data.mul_(2.0)
+    config.set_debug_packs(True)
+    try:
+        with pytest.raises(RuntimeError, match="no longer matches"):
+            ops.pack_weight(p.detach(), torch.bfloat16)
+        ops.invalidate_weight_packs()
+        fresh = ops.pack_weight(p.detach(), torch.bfloat16)
+        assert torch.equal(fresh, ops.pack_weight(p.detach().clone(), torch.bfloat16))
+        assert ops.pack_weight(p.detach(), torch.bfloat16) is fresh     # consistent again: no complaint
+    finally:
+        config.set_debug_packs(False)
+    del opt
+
+
+@pytest.mark.gpu
+def test_torch_sgd_checkpoint_keeps_exact_masters_restored_before():
+    """Resume order of tests/test_checkpoint.py with a torch.optim.SGD-written optimizer dict (no `master` entries):
+    load_full_precision_state_dict restores the exact fp32 masters first; load_state_dict must then leave them alone
+    (the bf16 copies still are their roundings) instead of overwriting them with the rounded values.  When the
+    weights were loaded into the parameters only, the masters follow the parameters."""
+    from segk.optim import SGD
+    dev = "cuda"
+    torch.manual_seed(4)
+    lin = torch.nn.Conv2d(16, 32, 3, bias=False).to(dev)
+    exact = torch.randn_like(lin.weight) * 1.2345
+    topt = torch.optim.SGD([torch.nn.Parameter(exact.clone())], lr=0.1, momentum=0.9)
+    topt.param_groups[0]["params"][0].grad = torch.ones_like(exact)
+    topt.step()
+    tsd = topt.state_dict()
+    opt = SGD(lin.parameters(), lr=0.1, momentum=0.9, low_precision=[lin.weight])
+    assert lin.weight.dtype == torch.bfloat16
+    opt.load_full_precision_state_dict(lin, {"weight": exact.clone()})
+    master = SGD._shaped(opt.state[lin.weight]["master"], lin.weight)
+    assert torch.equal(master, exact)
+    seen = []
+    opt.register_load_state_dict_pre_hook(lambda o, sd: seen.append("pre"))
+    opt.register_load_state_dict_post_hook(lambda o: seen.append("post"))
+    opt.load_state_dict(tsd)
+    assert seen == ["pre", "post"]
+    assert torch.equal(master, exact)                                     # not replaced by its bf16 rounding
+    assert torch.equal(lin.weight.detach(), exact.to(torch.bfloat16))
+    mom = SGD._shaped(opt.state[lin.weight]["momentum_buffer"], lin.weight)
+    assert torch.equal(mom, tsd["state"][0]["momentum_buffer"])
+    # weights loaded into the bf16 parameter only: the master is stale and is re-derived from the parameter
+    other = (torch.randn_like(exact) * 0.5).to(torch.bfloat16)
+    lin.weight.data.copy_(other)
+    opt.load_state_dict(tsd)
+    assert torch.equal(master, other.float())

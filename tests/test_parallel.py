@@ -116,6 +116,32 @@ def test_two_ranks_equal_one_rank_hip_modules():
 
 
 @pytest.mark.gpu
+def test_two_ranks_through_mailboxes_eager_and_graph_replay():
+    """The latency path: batch-norm statistics, loss sums and gradient buckets through the peer-mapped mailboxes
+    (two processes on one card map each other's mailbox by IPC handle).  Two ranks x half the batch equal one rank x
+    the whole batch as over gloo; then five SGD iterations, the last three replayed from a HIP graph on both ranks:
+    replayed losses equal the eagerly issued ones, and both ranks end with bit-identical weights (every rank added
+    the same vectors in the same order)."""
+    assert torch.cuda.is_available()
+    with tempfile.TemporaryDirectory() as d:
+        ranks = launch("mbx", 2, d)
+        single = launch("gpu", 1, d)[0]
+    _check_ranks_against_single(ranks, single, 1e-3)
+    for r in ranks:
+        assert r["exchanges"][0] > 100, r["exchanges"]     # the mailbox path carried them (a silent fall-back counts 0)
+        assert len(r["graph_losses"]) == 3
+        assert np.allclose(r["graph_losses"], r["eager_losses"], rtol=2e-4), (r["graph_losses"], r["eager_losses"])
+        assert r["eager_losses"][-1] < r["eager_losses"][0] * 1.5
+    assert np.array_equal(ranks[0]["graph_losses"], ranks[1]["graph_losses"])
+    for k in ranks[0]:
+        if k.startswith(("wg/", "we/")):
+            assert np.array_equal(ranks[0][k], ranks[1][k]), k
+    from helpers import rel_l2
+    worst = max(rel_l2(ranks[0]["wg/" + k[3:]], v) for k, v in ranks[0].items() if k.startswith("we/"))
+    assert worst < 5e-3, worst   # (the stand-in feeder's two MIOpen convolutions are not run-to-run deterministic)
+
+
+@pytest.mark.gpu
 def test_ranks_on_separate_devices_rccl():
     """One rank per device over RCCL (torch.distributed backend "nccl"): 2 devices x half the batch equal one
     device x the whole batch (/root/reference/train.py:105-110 with --gpu-ids 0,1)."""
