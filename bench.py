@@ -330,7 +330,11 @@ def main():
                                            overlap=world > 1 and args.optimizer == "hip")
         image, target = synthetic_batch(args.batch, args.size, args.classes, dev, 1 + rank)
 
-        use_graph = args.graph == "on" or (args.graph == "auto" and world == 1 and args.optimizer == "hip")
+        # (ranks > 1: only when every exchange of the step is a launch of this library - statistics, loss sums AND
+        # gradient buckets through the mailboxes, SEGK_GRAD_EXCHANGE=mailbox, a rehearsal path; with the buckets on
+        # RCCL the step is issued eagerly)
+        use_graph = args.optimizer == "hip" and (args.graph == "on" or (args.graph == "auto" and (
+            world == 1 or parallel.step_is_capturable())))
         config.set_overlap_wgrad(args.overlap_wgrad == "on" or (args.overlap_wgrad == "auto" and use_graph))
 
         def step(i):
@@ -359,7 +363,8 @@ def main():
             # stays on the host and reaches the recorded optimizer launch through device memory
             from segk.graph import GraphedTrainStep
             stepper = GraphedTrainStep(model, criterion, opt, image, target, warmup=warmup,
-                                       loss_fn=model.forward_loss if args.fused_loss else None)
+                                       loss_fn=model.forward_loss if args.fused_loss else None,
+                                       buckets=buckets if world > 1 else None)
             progress("%s: warm-up done (MIOpen algorithm search included), step recorded" % dtype)
 
             def run(i):
@@ -388,6 +393,8 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         progress("%s: %d timed steps, %.2f ms/step" % (dtype, steps, 1000.0 * elapsed / steps))
+        if world > 1:
+            parallel.check_exchange()   # raises if an in-kernel wait of the mailbox path timed out
         res = {"final_loss": float(loss.detach()), "feeder_amp": feeder_amp, "conv": None, "hbm": None,
                "graph": use_graph}
         if detailed and use_graph:
@@ -493,6 +500,7 @@ def main():
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "collectives": ("RCCL (torch.distributed nccl backend)" if backend == "nccl" else backend) if world > 1 else None,
+                       "small_exchanges": parallel.exchange_description(),
                        "launch": ("one HIP graph per training iteration (segk.graph.GraphedTrainStep): recorded after the "
                                   "warm-up, replayed in the timed region; learning-rate schedule on the host"
                                   if main_res["graph"] else "eager: one host call per kernel launch"),

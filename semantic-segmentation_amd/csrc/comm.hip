@@ -128,7 +128,7 @@ namespace segk {
 
 constexpr int MBX_MAX_WORLD = 16;
 constexpr int MBX_HEADER_BYTES = 512;
-constexpr int MBX_THREADS = 1024;
+constexpr int MBX_THREADS = 512;
 
 struct MailboxPeers {
   char* base[MBX_MAX_WORLD];
@@ -182,28 +182,32 @@ __global__ __launch_bounds__(MBX_THREADS) void mailbox_allreduce_kernel(const Ma
       for (int i = tid; i < cn; i += MBX_THREADS)
         __hip_atomic_store(dst + i, (double)part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __threadfence_system();
+    // (the stores above are write-through; every storing wavefront waits for its own, the workgroup meets, and
+    // only the lanes that raise a flag pay for a release - a system-scope fence in all 512 threads costs
+    // microseconds)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid < a.world)
       __hip_atomic_store(mbx_flag(a.base[tid], phase, a.rank), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    // wait for every rank's delivery into the own mailbox (bounded)
+    // wait for every rank's delivery into the own mailbox: relaxed polls, one acquire once the flag is up (bounded)
     if (tid < a.world) {
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
       unsigned long long* f = mbx_flag(own, phase, tid);
-      while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-        __builtin_amdgcn_s_sleep(8);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
+      unsigned polls = 0;
+      while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++polls & 63u) == 0u && __builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
           atomicExch(&s_fail, 1);
           break;
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     }
     __syncthreads();
     if (s_fail) {
       if (tid == 0) __hip_atomic_store(status, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       break;
     }
-    __threadfence_system();
     // the sum, in rank order on every rank
     for (int i = tid; i < cn; i += MBX_THREADS) {
       double s = 0.0;
