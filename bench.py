@@ -207,6 +207,34 @@ def torch_rocm_baseline(args, dev):
     return out
 
 
+def calibrated_hbm_peak(dev, gib=1.0, reps=5):
+    """What a plain device-to-device copy reaches on this GPU right now: GB/s of bytes read + bytes written by
+    `dst.copy_(src)` over `gib` GiB (median of `reps`, after one warm-up), timed with HIP events.  The memory-bound
+    kernels are reported against the nominal 8 TB/s AND against this figure."""
+    n = int(gib * (1 << 30))
+    src = torch.empty(n, dtype=torch.uint8, device=dev)
+    dst = torch.empty(n, dtype=torch.uint8, device=dev)
+    src.fill_(1)
+    dst.copy_(src)
+    times = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        dst.copy_(src)
+        b.record()
+        torch.cuda.synchronize()
+        times.append(a.elapsed_time(b))
+    del src, dst
+    torch.cuda.empty_cache()
+    return 2.0 * n / (float(np.median(times)) * 1e-3) / 1e9
+
+
+def _file_sha1(path):
+    import hashlib
+    with open(path, "rb") as f:
+        return hashlib.sha1(f.read()).hexdigest()
+
+
 def measured_traffic(args, families, calls_per_step):
     """HBM bytes per library call of the kernel `families` from the committed rocprofv3 counter passes
     (tools/pmc_traffic.sh: one FETCH_SIZE pass and one WRITE_SIZE pass over this same bench command, FETCH_SIZE
@@ -215,16 +243,26 @@ def measured_traffic(args, families, calls_per_step):
     so the figure is read from profiles/; it applies to the default workload only."""
     default = (args.batch, args.size, args.classes, args.out_stride, args.dtype) == (16, 513, 21, 16, "bf16")
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not default or not os.path.exists(path) or calls_per_step <= 0:
-        return None
+    if not default:
+        return None, "counter passes exist for the default workload only"
+    if not os.path.exists(path) or calls_per_step <= 0:
+        return None, "no counter passes committed"
     try:
         with open(path) as f:
             doc = json.load(f)
+        # the passes are only as fresh as the kernels they profiled: the file records the hash of the convolution
+        # source it was collected with (tools/pmc_traffic.sh), and a different source today voids the figure
+        now = _file_sha1(os.path.join(ROOT, "semantic-segmentation_amd", "csrc", "conv.hip"))
+        if doc.get("conv_hip_sha1") != now:
+            return None, ("stale: profiles/pmc_traffic.json was collected with conv.hip %s, this tree has %s; "
+                          "run tools/pmc_traffic.sh again" % (str(doc.get("conv_hip_sha1"))[:12], now[:12]))
         total = sum(float(doc["kernels"][k]["launches"]) * float(doc["kernels"][k]["hbm_bytes_per_launch"])
                     for k in families if k in doc["kernels"])
-        return total / (float(doc.get("bench_steps", 3)) * calls_per_step) if total > 0 else None
-    except (KeyError, ValueError, OSError):
-        return None
+        if total <= 0:
+            return None, "the counter passes hold no launch of these kernels"
+        return total / (float(doc.get("bench_steps", 3)) * calls_per_step), None
+    except (KeyError, ValueError, OSError) as e:
+        return None, "unreadable counter passes: %s" % e
 
 
 def spawn_ranks(args):
@@ -449,6 +487,12 @@ def main():
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                "traffic": None,
+                               # nominal FLOPs count every tap, also those that read the zero padding; this is the
+                               # share of them whose tap lies inside the image (dilations 6 / 12 / 18 on 33 x 33 maps
+                               # leave 0.77 / 0.57 / 0.40 of a 3 x 3) - the kernels skip a tap only where it misses
+                               # the image for a whole tile, so they execute at least this share
+                               "inbounds_flops_frac": dom.get("flops_inbounds", dom["flops"]) / dom["flops"],
+                               "achieved_inbounds": ach * dom.get("flops_inbounds", dom["flops"]) / dom["flops"],
                                "kernel": "conv_fwd_ring_kernel (bf16) / conv_fwd_dma_kernel / conv_fwd_kernel (implicit-GEMM forward + data "
                                "gradient, all %d segk_conv_fwd calls of the head in the timed steps, each bracketed by two HIP events "
                                "on the launch stream; a call is one launch or a main + tail pair)" % dom["launches"],
@@ -457,6 +501,7 @@ def main():
         if wg:
             ach = wg["flops"] / (wg["ms"] * 1e-3) / 1e12
             out["roofline_wgrad"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                                     "inbounds_flops_frac": wg.get("flops_inbounds", wg["flops"]) / wg["flops"],
                                      "avg_launch_ms": wg["avg_ms"],
                                      "kernel": "conv_wgrad_ring_kernel (bf16, 256 output channels) / conv_wgrad_kernel / conv_wgrad_dma_kernel + wgrad_finish_kernel (%d "
                                                "weight gradients of the head: the split-slab launch and the fixed-order "
@@ -515,18 +560,25 @@ def main():
             line.update(conv_rooflines(main_res, args.dtype, args.steps, elapsed))
             if "roofline" in line:
                 calls = main_res["conv"]["conv_fwd_kernel"]["launches"] / float(args.steps)
-                line["roofline"]["traffic"] = measured_traffic(args, ("conv_fwd_ring_kernel", "conv_fwd_dma_kernel", "conv_fwd_kernel"), calls)
+                traffic, why = measured_traffic(args, ("conv_fwd_ring_kernel", "conv_fwd_dma_kernel", "conv_fwd_kernel"), calls)
+                line["roofline"]["traffic"] = traffic
+                if traffic is None:
+                    line["roofline"]["traffic_note"] = why
                 line["roofline"]["traffic_unit"] = ("HBM bytes per segk_conv_fwd call (rocprofv3 FETCH_SIZE x2 + "
                                                     "WRITE_SIZE, profiles/pmc_traffic.json: counter passes with the feeder on MIOpen, "
                                                     "so that only the head's launches are counted)")
             summ = main_res["hbm"]
             step_ms = 1000.0 * elapsed / args.steps
+            hbm_cal = calibrated_hbm_peak(dev)
+            progress("device copy of 1 GiB: %.0f GB/s (read + written)" % hbm_cal)
             bn = [v for k, v in summ.items() if k.startswith("bn_")]
             if bn:
                 nbytes, ms = sum(v["flops"] for v in bn), sum(v["ms"] for v in bn)
                 ach = nbytes / (ms * 1e-3) / 1e9
                 line["roofline_hbm"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": ach / HBM_PEAK_GBS,
+                                        "hbm_peak_calibrated": hbm_cal, "frac_of_calibrated": ach / hbm_cal,
+                                        "calibration": "1 GiB device-to-device copy in this run, bytes read + written",
                                         "kernel": "bn_stats / bn_apply / bn_bwd_stats / bn_bwd_apply (pixel-major batch "
                                                   "norm, %d launches of one extra step after the timed region; algorithmic bytes = every "
                                                   "operand tensor once)" % sum(v["launches"] for v in bn),
@@ -540,11 +592,13 @@ def main():
                 v = (summ if in_step else main_res["eval"]).get(name)
                 if v and v["ms"] > 0:
                     ach = v["flops"] / (v["ms"] * 1e-3) / 1e9
-                    others[name] = {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "launches": v["launches"],
+                    others[name] = {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "frac_of_calibrated": ach / hbm_cal,
+                                    "launches": v["launches"],
                                     "avg_launch_ms": v["avg_ms"], "bytes_per_launch": v["flops"] / v["launches"],
                                     "in_step": in_step}
             if others:
-                line["roofline_hbm_kernels"] = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernels": others,
+                line["roofline_hbm_kernels"] = {"bound": "hbm", "peak": HBM_PEAK_GBS, "hbm_peak_calibrated": hbm_cal,
+                                                "unit": "GB/s", "kernels": others,
                                                 "note": "argmax / confmat / upsample_argmax: evaluation leg after the "
                                                         "timed region (Evaluator.add_logits, add_low_logits), not part of `value`"}
         default_workload = world == 1 and args.config == "A"

@@ -18,17 +18,18 @@ __all__ = ["SynchronizedBatchNorm1d", "SynchronizedBatchNorm2d", "SynchronizedBa
 def conv_is_hip_eligible(conv):
     """The static part of can_fuse_conv: the stride-1 bottleneck 3x3 convolutions of ResNet layers 2 to 4 (128
     channels and up; measured GPU time per unit, forward + statistics + both gradients, bf16, batch 16 at output
-    stride 16: 118 against 169 us at 128 channels, 101 / 181 at 256, 284 / 443 at 512) and the 1x1 convolutions that
-    reduce 1024 or more channels (conv1 of the bottlenecks of layers 3 and 4: 79 / 114 us for 1024 -> 256, 173 / 237
-    for 2048 -> 512).  The 64-channel convolutions of layer 1 and the narrower 1x1 convolutions are level or faster
-    on the vendor kernels (512 -> 128 at 65 x 65: 113 / 115)."""
+    stride 16, HIP against PyTorch-ROCm: 110 / 170 us at 128 channels, 91 / 181 at 256, 253 / 448 at 512) and the 1x1
+    convolutions that reduce 256 or more channels (conv1 of the bottlenecks: 160 / 172 us for 256 -> 64 at 129 x 129,
+    99 / 114 for 512 -> 128 at 65 x 65, 70 / 105 for 1024 -> 256, 154 / 231 for 2048 -> 512).  The 64-channel 3x3
+    convolutions of layer 1 stay on the vendor kernels."""
     if not (conv.stride == (1, 1) and conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros"
-            and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0 and conv.out_channels >= 128):
+            and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0):
         return False
     if conv.kernel_size == (3, 3):
-        return conv.padding == conv.dilation and conv.dilation[0] == conv.dilation[1] and conv.in_channels >= 128
+        return (conv.padding == conv.dilation and conv.dilation[0] == conv.dilation[1] and conv.in_channels >= 128
+                and conv.out_channels >= 128)
     if conv.kernel_size == (1, 1):
-        return conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.in_channels >= 1024
+        return conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.in_channels >= 256 and conv.out_channels >= 64
     return False
 
 
@@ -67,7 +68,7 @@ class _SynchronizedBatchNorm(_BatchNorm):
 
     def can_fuse_conv(self, conv, input):
         """Whether forward_conv_relu(conv, input) applies: a stride-1 3x3 convolution with padding = dilation and 128
-        or more channels on both sides, or a 1x1 convolution from 1024 or more channels onto 128 or more (no bias,
+        or more channels on both sides, or a 1x1 convolution from 256 or more channels onto 64 or more (no bias,
         channel counts multiples of 32), a GPU tensor, and the mode set with segk.config.set_feeder_conv."""
         from ... import config
         mode = config.feeder_conv()
@@ -87,20 +88,21 @@ class _SynchronizedBatchNorm(_BatchNorm):
         return SF.ConvBNReLUFunction.apply(input, conv.weight, self.weight, self.bias, conv, self)
 
     def can_fuse_conv_residual(self, conv, input, residual):
-        """Whether forward_conv_add_relu(conv, input, residual) applies: a 1x1 convolution from 256 or more channels
-        onto 1024 or more (conv3 of the bottlenecks of ResNet layers 3 and 4; measured per unit as in
-        conv_is_hip_eligible: 87 against 104 us for 256 -> 1024, 184 / 251 for 512 -> 2048; 128 -> 512 at 65 x 65 is
-        level), channels_last GPU tensors of one dtype, and the mode set with segk.config.set_feeder_conv."""
+        """Whether forward_conv_add_relu(conv, input, residual) applies: a 1x1 convolution from 128 or more channels
+        onto 512 or more (conv3 of the bottlenecks of ResNet layers 2 to 4; measured per unit as in
+        conv_is_hip_eligible: 94 against 117 us for 128 -> 512 at 65 x 65, 74 / 104 for 256 -> 1024, 159 / 252 for
+        512 -> 2048; 64 -> 256 at 129 x 129 is 166 / 157 and stays on the vendor kernels), channels_last GPU tensors
+        of one dtype, and the mode set with segk.config.set_feeder_conv."""
         from ... import config
         T = SF.torch
         if config.feeder_conv() == "torch" or not (isinstance(input, T.Tensor) and input.is_cuda and input.dim() == 4):
             return False
         if not (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
-                and conv.dilation == (1, 1) and conv.bias is None and conv.in_channels >= 256
-                and conv.in_channels % 32 == 0 and conv.out_channels >= 1024 and conv.out_channels % 32 == 0
+                and conv.dilation == (1, 1) and conv.bias is None and conv.in_channels >= 128
+                and conv.in_channels % 32 == 0 and conv.out_channels >= 512 and conv.out_channels % 32 == 0
                 and conv.out_channels == self.num_features):
             return False
-        cd = T.bfloat16 if (input.dtype == T.bfloat16 or T.is_autocast_enabled()) else T.float32
+        cd = SF._feeder_compute_dtype(input)
         return (input.dtype in (T.float32, T.bfloat16) and isinstance(residual, T.Tensor) and residual.dtype == cd
                 and tuple(residual.shape) == (input.shape[0], conv.out_channels, input.shape[2], input.shape[3])
                 and SF.pm_view_of(input) is not None and not input.is_contiguous()

@@ -76,18 +76,21 @@ class KernelTimer:
         e.record()
         return e
 
-    def stop(self, name, flops, start):
+    def stop(self, name, flops, start, inbounds=None):
+        """inbounds: the part of `flops` whose kernel taps fall inside the image (convolutions; default: all)."""
         e = torch.cuda.Event(enable_timing=True)
         e.record()
-        self.records.setdefault(name + self.scope, []).append((flops, start, e))
+        self.records.setdefault(name + self.scope, []).append((flops, start, e, flops if inbounds is None else inbounds))
 
     def summary(self):
-        """name -> dict(launches, flops (sum), ms (sum), avg_ms); call after torch.cuda.synchronize()."""
+        """name -> dict(launches, flops (sum), flops_inbounds (sum), ms (sum), avg_ms); call after
+        torch.cuda.synchronize()."""
         out = {}
         for name, recs in self.records.items():
-            ms = sum(s.elapsed_time(e) for _, s, e in recs)
-            fl = sum(f for f, _, _ in recs)
-            out[name] = {"launches": len(recs), "flops": fl, "ms": ms, "avg_ms": ms / max(len(recs), 1)}
+            ms = sum(r[1].elapsed_time(r[2]) for r in recs)
+            fl = sum(r[0] for r in recs)
+            out[name] = {"launches": len(recs), "flops": fl, "flops_inbounds": sum(r[3] for r in recs), "ms": ms,
+                         "avg_ms": ms / max(len(recs), 1)}
         return out
 
 
@@ -110,6 +113,16 @@ class scoped:
     def __exit__(self, *exc):
         if self.timer is not None:
             self.timer.scope = self.old
+
+
+def inbounds_fraction(H, W, R, dil):
+    """Share of the R x R taps of a stride-1, padding = dilation convolution on an H x W map that read inside the
+    image, over all pixels: tap offset (dy, dx) is in bounds for (H - |dy|)(W - |dx|) pixels."""
+    if R == 1:
+        return 1.0
+    rows = H + 2 * max(H - dil, 0)
+    cols = W + 2 * max(W - dil, 0)
+    return rows * cols / float(R * R * H * W)
 
 
 def _hbm_start():
@@ -449,8 +462,13 @@ def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=Fals
     call("segk_conv_fwd", ctypes.byref(a), _stream())
     if t0 is not None:
         # nominal FLOPs: every tap counted (also the ones that fall outside the image), padded channels not
-        fl = max(batch, 1) * sum(2.0 * M * Cout * timer_ck[i] * segs[i][2] ** 2 for i in range(len(segs)))
-        TIMER.stop("conv_fwd_kernel", fl, t0)
+        fl = inb = 0.0
+        for b in range(max(batch, 1)):
+            for i in range(len(segs)):
+                f = 2.0 * M * Cout * timer_ck[i] * segs[i][2] ** 2
+                fl += f
+                inb += f * inbounds_fraction(H, W, segs[i][2], segs[i][3] + b * dil_step)
+        TIMER.stop("conv_fwd_kernel", fl, t0, inbounds=inb)
     return stats
 
 
@@ -543,7 +561,8 @@ def conv_wgrad(x, dout, N, H, W, R, dil, Cout_true, Cin_true, splits=None, like=
     call("segk_wgrad_finish_strided", _ptr(slabs), splits, R, Cin, Cout, _ptr(dw), _dt(dw), s_co, s_ci, s_tap,
          Cout_true, Cin_true, _stream())
     if t0 is not None:
-        TIMER.stop("conv_wgrad_kernel", 2.0 * M * Cout_true * Cin_true * R * R, t0)
+        fl = 2.0 * M * Cout_true * Cin_true * R * R
+        TIMER.stop("conv_wgrad_kernel", fl, t0, inbounds=fl * inbounds_fraction(H, W, R, dil))
     return dw
 
 

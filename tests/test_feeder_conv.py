@@ -114,7 +114,8 @@ def test_unit_1x1_bf16_channels_last():
     conv.weight.data = conv.weight.data.to(torch.bfloat16)
     xd = x.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     assert bn.can_fuse_conv(conv, xd)
-    assert not SynchronizedBatchNorm2d(128).to(dev).can_fuse_conv(nn.Conv2d(512, 128, 1, bias=False).to(dev), xd[:, :512])
+    assert SynchronizedBatchNorm2d(128).to(dev).can_fuse_conv(nn.Conv2d(512, 128, 1, bias=False).to(dev), xd[:, :512])
+    assert not SynchronizedBatchNorm2d(64).to(dev).can_fuse_conv(nn.Conv2d(64, 64, 1, bias=False).to(dev), xd[:, :64])
     with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
         y = bn.forward_conv_relu(conv, xd)
     assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
@@ -134,7 +135,7 @@ def test_unit_1x1_bf16_channels_last():
 
 def test_unit_1x1_residual_bf16_channels_last():
     """conv3 -> bn3 -> += residual -> relu of a layer-3 bottleneck (1x1, 256 -> 1024) as one unit, gradient of the
-    residual included; 128 -> 512 stays on the PyTorch path."""
+    residual included; 64 -> 256 (ResNet layer 1) stays on the PyTorch path."""
     from segk.modeling.sync_batchnorm import SynchronizedBatchNorm2d
     dev, Cin, Cout, n, h, w = "cuda", 256, 1024, 3, 9, 11
     x = torch.from_numpy(gen.relu_normal(SEED, "f3/x", (n, Cin, h, w)))
@@ -154,8 +155,8 @@ def test_unit_1x1_residual_bf16_channels_last():
     xd, rd = cl(x), cl(res)
     assert bn.can_fuse_conv_residual(conv, xd, rd)
     assert not bn.can_fuse_conv_residual(conv, xd, rd.detach().float())
-    small = nn.Conv2d(128, 512, 1, bias=False).to(dev)
-    assert not SynchronizedBatchNorm2d(512).to(dev).can_fuse_conv_residual(small, xd[:, :128], rd[:, :512])
+    small = nn.Conv2d(64, 256, 1, bias=False).to(dev)
+    assert not SynchronizedBatchNorm2d(256).to(dev).can_fuse_conv_residual(small, xd[:, :64], rd[:, :256])
     with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
         y = bn.forward_conv_add_relu(conv, xd, rd)
     assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)

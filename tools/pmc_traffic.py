@@ -43,8 +43,15 @@ def main():
         out[k] = {"launches": nf.get(k, 0), "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                   "hbm_bytes_per_launch": rd + wr}
     # tools/pmc_traffic.sh profiles `bench.py --steps 2 --warmup 1`: three steps
-    json.dump({"unit": "bytes per launch (FETCH_SIZE x2 x1024, WRITE_SIZE x1024)", "bench_steps": 3, "kernels": out},
-              sys.stdout, indent=1)
+    # the hash of the convolution source these passes profiled: bench.py reports the figures only while it stands
+    import hashlib
+    import os
+    conv = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "semantic-segmentation_amd", "csrc",
+                        "conv.hip")
+    with open(conv, "rb") as f:
+        sha = hashlib.sha1(f.read()).hexdigest()
+    json.dump({"unit": "bytes per launch (FETCH_SIZE x2 x1024, WRITE_SIZE x1024)", "bench_steps": 3,
+               "conv_hip_sha1": sha, "kernels": out}, sys.stdout, indent=1)
 
 
 if __name__ == "__main__":
