@@ -123,6 +123,13 @@ typedef struct {
   long long w_batch;
   long long out_batch;
   int dil_step;
+  /* NULL, or [M][addend_ld] of out_dtype: out = round(conv) + addend, the conv result rounded to out_dtype first
+   * (bit for bit what a separate addition of the two tensors gives).  It stands for the addition autograd performs
+   * where a bottleneck's input receives two gradients - from conv1's data gradient and from the shortcut
+   * (newmodeling/backbone/resnet101_2.py:31-51, `out += residual`).  Needs bf16 operands with 128-byte K rows, Cout
+   * a multiple of 128, no biases, batch <= 1; SEGK_UNSUPPORTED_SHAPE otherwise. */
+  const void* addend;
+  int addend_ld;
 } segk_conv_args;
 
 /* nn.Conv2d forward (modeling/aspp.py:18, modeling/decoder.py:172,178) and, with transposed packed

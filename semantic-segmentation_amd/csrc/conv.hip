@@ -63,6 +63,8 @@ struct ConvDev {
   long long stat_batch;  // doubles between the statistic partials of consecutive batch entries
   const float* bias;
   const float* img_bias;
+  const char* addend;    // nullptr, or [M][addend_ld] of the output dtype, added to the rounded result (ring tile only)
+  long long addend_ld_b;
   double* stat;
   long long m_begin;     // first pixel of this launch (a problem may be cut into a main and a tail launch)
   long long stat_row0;   // statistic partial row of this launch's first pixel tile
@@ -115,6 +117,13 @@ template <>
 __device__ __forceinline__ void store_out4<bf16_t>(char* p, const float (&v)[4]) {
   u32x2 t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
   *reinterpret_cast<u32x2*>(p) = t;
+}
+
+// a + b of two packed bf16 pairs, each lane rounded once more to bf16: what adding two bf16 tensors gives
+__device__ __forceinline__ unsigned int add_bf16x2(unsigned int a, unsigned int b) {
+  const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
+  const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u);
+  return pack_bf16x2(lo, hi);
 }
 
 // Tile geometry: a workgroup owns BCO output channels x BPX pixels with WCO x WPX wavefronts; each wavefront
@@ -2057,7 +2066,8 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
     const bool plain = __builtin_amdgcn_readfirstlane((co0 + BCO <= p.Cout && !p.bias && !p.img_bias) ? 1 : 0) != 0;
     if (plain) {
       if constexpr (sizeof(TO) == 2) {
-        const bool wide16 = __builtin_amdgcn_readfirstlane(((((uintptr_t)obase) & 15) == 0 && (p.out_ld & 7) == 0) ? 1 : 0) != 0;
+        const bool wide16 = __builtin_amdgcn_readfirstlane(((((uintptr_t)obase) & 15) == 0 && (p.out_ld & 7) == 0 &&
+                                                             (!p.addend || ((((uintptr_t)p.addend) | (uintptr_t)p.addend_ld_b) & 15) == 0)) ? 1 : 0) != 0;
         if (wide16) {
           const int cbase = co0 + wr * (MI * 16) + ((fg & 1) ? 16 + (fg - 1) * 4 : fg * 4);
 #pragma unroll
@@ -2070,8 +2080,15 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
               unsigned b0 = pack_bf16x2(acc[i + 1][j][0], acc[i + 1][j][1]), b1 = pack_bf16x2(acc[i + 1][j][2], acc[i + 1][j][3]);
               const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
               const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
-              const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-              if (m < p.M) *reinterpret_cast<u32x4*>(orow + i * 32) = o;
+              u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+              if (m < p.M) {
+                if (p.addend) {
+                  const u32x4 ad = *reinterpret_cast<const u32x4*>(p.addend + (size_t)m * p.addend_ld_b + (size_t)cbase * 2 + i * 32);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) o[e] = add_bf16x2(o[e], ad[e]);
+                }
+                *reinterpret_cast<u32x4*>(orow + i * 32) = o;
+              }
             }
           }
           continue;
@@ -2081,10 +2098,25 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
       for (int j = 0; j < MJ; ++j) {
         const long long m = m0 + wc * (MJ * 16) + j * 16 + frow;
         if (m >= p.M) continue;
-        char* orow = obase + ((size_t)m * p.out_ld + co0 + wr * (MI * 16) + fg * 4) * sizeof(TO);
+        const size_t coff = (size_t)(co0 + wr * (MI * 16) + fg * 4) * sizeof(TO);
+        char* orow = obase + (size_t)m * p.out_ld * sizeof(TO) + coff;
+        const char* arow = p.addend ? p.addend + (size_t)m * p.addend_ld_b + coff : nullptr;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-          const float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          if (arow) {
+            if constexpr (sizeof(TO) == 2) {
+              const u32x2 ad = *reinterpret_cast<const u32x2*>(arow + i * 32);
+              const unsigned r0 = add_bf16x2(pack_bf16x2(o[0], o[1]), ad[0]), r1 = add_bf16x2(pack_bf16x2(o[2], o[3]), ad[1]);
+              const u32x2 t = {r0, r1};
+              *reinterpret_cast<u32x2*>(orow + i * 32) = t;
+              continue;
+            } else {
+              const f32x4 ad = *reinterpret_cast<const f32x4*>(arow + i * 64);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[r] += ad[r];
+            }
+          }
           store_out4<TO>(orow + i * 16 * sizeof(TO), o);
         }
       }
@@ -2697,6 +2729,8 @@ static bool fill_dev(const segk_conv_args* a, ConvDev& d) {
   d.stat_batch = 0;  // set once the tile geometry (= number of partial rows) is known
   d.m_begin = 0; d.stat_row0 = 0;
   d.bias = a->bias; d.img_bias = a->img_bias; d.stat = a->stat_partials;
+  d.addend = (const char*)a->addend;
+  d.addend_ld_b = (long long)a->addend_ld * dtype_size(a->out_dtype);
   return wide;
 }
 
@@ -2718,6 +2752,13 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
                "conv: batch=%d (biases are not batched)", batch);
   const TilePlan plan = plan_tiles(d, wide, batch, a->dtype == SEGK_BF16);
   const bool big = plan.big;
+  if (a->addend) {
+    SEGK_REQUIRE(a->addend_ld >= a->Cout && ((uintptr_t)a->addend % (a->out_dtype == SEGK_BF16 ? 8 : 16)) == 0 &&
+                     ((long long)a->addend_ld * dtype_size(a->out_dtype)) % (a->out_dtype == SEGK_BF16 ? 8 : 16) == 0,
+                 "conv: addend misaligned or addend_ld=%d < Cout=%d", a->addend_ld, a->Cout);
+    SEGK_UNSUPPORTED(plan.ring && a->Cout % 128 == 0 && !a->bias && !a->img_bias && batch == 1,
+                     "conv: an addend needs bf16 operands with 128-byte K rows, Cout a multiple of 128 and no biases");
+  }
   d.stat_batch = (long long)plan_stat_rows(d, plan) * 2 * d.Cout;
   hipStream_t st = (hipStream_t)stream;
 #ifdef SEGK_EXPERIMENTS
@@ -2897,6 +2938,7 @@ extern "C" int segk_gemm_nt(const segk_gemm_args* a, segk_stream_t stream) {
   d.dil_step = 0; d.stat_batch = 0;
   d.m_begin = 0; d.stat_row0 = 0;
   d.bias = nullptr; d.img_bias = nullptr; d.stat = nullptr;
+  d.addend = nullptr; d.addend_ld_b = 0;
   const long long big_tiles = (long long)ceil_div(a->M, TileBig::BPX) * (a->N / TileBig::BCO) * a->batch;
   const bool big = wide && a->N % TileBig::BCO == 0 && big_tiles >= 512;
   static const char* gemm_env = experiment("SEGK_GEMM_DMA");

@@ -285,17 +285,24 @@ def unit_backward(rec, dz, need_dw=True, dw_like=None):
     return dy, dw, dgamma, dbeta
 
 
-def dgrad(items, geom, Cin, out_dtype, img_bias=None):
+def dgrad(items, geom, Cin, out_dtype, img_bias=None, addend=None):
     """Data gradient of one or several convolutions that share their input: items = [(dy, weight, R, dil)].
-    Returns a pixel-major [M, Cin rounded up to 4] tensor of out_dtype."""
+    Returns a pixel-major [M, Cin rounded up to 4] tensor of out_dtype.  addend (a pixel-major view of out_dtype, or
+    None): another gradient of the same input, added in the convolution's epilogue when the kernels can
+    (ops.conv_addend_ok) and by a separate addition otherwise - the same bits either way."""
     N, H, W = geom
     segs = []
     for dy, weight, R, dil in items:
         segs.append((dy, ops.pack_weight(weight.detach(), dy.dtype, transpose=True), R, dil))
     cpad = ops.round_up(Cin, 4)
     out = torch.empty((N * H * W, cpad), dtype=out_dtype, device=items[0][0].device)
-    ops.conv_fwd(segs, N, H, W, Cin, out, img_bias=img_bias, true_ck=[it[1].shape[0] for it in items])
-    return out[:, :Cin] if cpad != Cin else out
+    fused = addend is not None and img_bias is None and ops.conv_addend_ok(segs, Cin, out_dtype, addend)
+    ops.conv_fwd(segs, N, H, W, Cin, out, img_bias=img_bias, true_ck=[it[1].shape[0] for it in items],
+                 addend=addend if fused else None)
+    res = out[:, :Cin] if cpad != Cin else out
+    if addend is not None and not fused:
+        res = res + addend[:, :Cin]
+    return res
 
 
 def _padded_input(v, mult=32):
@@ -648,7 +655,9 @@ class SyncBNFunction(torch.autograd.Function):
     that follows it, and with the residual that a bottleneck block adds in between, in the same passes."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, mod, relu=False, residual=None):
+    def forward(ctx, x, gamma, beta, mod, relu=False, residual=None, grad_slot=None):
+        """grad_slot (GradSlot or None): where the residual's gradient goes instead of back through autograd."""
+        ctx.grad_slot = grad_slot
         spec = _BNSpec(mod)
         layout, xv, shape = NCHW, x, x.shape
         v = pm_view_of(x) if x.dim() == 4 else None
@@ -718,7 +727,10 @@ class SyncBNFunction(torch.autograd.Function):
             dx = dx.to(in_dtype)
         if not ctx.affine:
             dgamma = dbeta = None
-        return dx, dgamma, dbeta, None, None, dres
+        if ctx.grad_slot is not None and dres is not None and ctx.needs_input_grad[5]:
+            ctx.grad_slot.put(dres)
+            dres = None
+        return dx, dgamma, dbeta, None, None, dres, None
 
 
 def _feeder_compute_dtype(x):
@@ -737,6 +749,24 @@ def _vector_aligned(v):
     return v if _pm_aligned8(v) else v.contiguous()
 
 
+class GradSlot:
+    """Hand-over of one gradient between the two backward functions of a bottleneck block whose input x feeds both
+    conv1 and the shortcut: the function that produces the shortcut's gradient (it runs first in backward) leaves it
+    here instead of returning it to autograd, and conv1's function adds it inside its data-gradient convolution, so
+    x receives ONE gradient and autograd's separate addition of two 36 - 136 MB tensors per block disappears."""
+    __slots__ = ("grad",)
+
+    def __init__(self):
+        self.grad = None
+
+    def put(self, g):
+        self.grad = g
+
+    def take(self):
+        g, self.grad = self.grad, None
+        return g
+
+
 # ------------------------------------------------- feeder conv + BN + ReLU ----
 class ConvBNReLUFunction(torch.autograd.Function):
     """relu(bn(conv(x))) of a feeder bottleneck block (newmodeling/backbone/resnet101_2.py:19-21 and
@@ -749,7 +779,8 @@ class ConvBNReLUFunction(torch.autograd.Function):
     in the weight's own dtype and layout."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, conv, bn):
+    def forward(ctx, x, weight, gamma, beta, conv, bn, grad_slot=None):
+        """grad_slot (GradSlot or None): a second gradient of x that another function of the block leaves there."""
         N, Cin, H, W = x.shape
         R, dil = conv.kernel_size[0], conv.dilation[0]
         cd = _feeder_compute_dtype(x)
@@ -765,7 +796,7 @@ class ConvBNReLUFunction(torch.autograd.Function):
             stats = ops.conv_fwd([(xv, w_op, R, dil)], N, H, W, Cout, raw, want_stats=spec.training, true_ck=[Cin])
         y = torch.empty((N, Cout, H, W), dtype=cd, device=x.device, memory_format=torch.channels_last)
         rec = unit_finish(xv, raw, stats, weight, R, dil, (N, H, W), spec, gamma, beta, pm_view_of(y), relu=True)
-        ctx.rec, ctx.x = rec, x
+        ctx.rec, ctx.x, ctx.grad_slot = rec, x, grad_slot
         if pm_view_of(x) is None or x.is_contiguous():   # hand an NCHW caller an NCHW tensor back
             y = y.contiguous()
         return y if y.dtype == x.dtype or torch.is_autocast_enabled() else y.to(x.dtype)
@@ -778,10 +809,21 @@ class ConvBNReLUFunction(torch.autograd.Function):
             dy, dw, dgamma, dbeta = unit_backward(rec, to_pm(g, rec.x.dtype), need_dw=ctx.needs_input_grad[1],
                                                   dw_like=rec.weight)
             dx = None
+            other = ctx.grad_slot.take() if ctx.grad_slot is not None else None
             if ctx.needs_input_grad[0]:
-                dxp = dgrad([(dy, rec.weight, rec.R, rec.dil)], rec.geom, rec.Cin, grad_dtype_for(x))
+                gd = grad_dtype_for(x)
+                ov = pm_view_of(other) if other is not None else None
+                if other is not None and (ov is None or ov.dtype != gd):
+                    ov, late = None, other          # not a pixel-major tensor of the gradient's dtype: add afterwards
+                else:
+                    late = None
+                dxp = dgrad([(dy, rec.weight, rec.R, rec.dil)], rec.geom, rec.Cin, gd, addend=ov)
                 dx = grad_like(x, dxp, N, H, W)
-        return dx, dw, dgamma, dbeta, None, None
+                if late is not None:
+                    dx = dx + late.to(dx.dtype)
+            elif other is not None:
+                raise RuntimeError("a gradient was left for an input that needs none")
+        return dx, dw, dgamma, dbeta, None, None, None
 
 
 class ConvBNAddReLUFunction(torch.autograd.Function):
@@ -792,7 +834,9 @@ class ConvBNAddReLUFunction(torch.autograd.Function):
     data-gradient convolution.  Channels_last operands of one dtype."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, residual, conv, bn):
+    def forward(ctx, x, weight, gamma, beta, residual, conv, bn, grad_slot=None):
+        """grad_slot (GradSlot or None): where the residual's gradient goes instead of back through autograd."""
+        ctx.grad_slot = grad_slot
         N, Cin, H, W = x.shape
         R, dil = conv.kernel_size[0], conv.dilation[0]
         cd = _feeder_compute_dtype(x)
@@ -846,7 +890,10 @@ class ConvBNAddReLUFunction(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dxp = dgrad([(dy, weight, R, dil)], geom, Cin, grad_dtype_for(x))
                 dx = grad_like(x, dxp, N, H, W)
-        return dx, dw, dgamma, dbeta, (dres if ctx.needs_input_grad[4] else None), None, None
+        if ctx.grad_slot is not None and ctx.needs_input_grad[4]:
+            ctx.grad_slot.put(dres)
+            dres = None
+        return dx, dw, dgamma, dbeta, (dres if ctx.needs_input_grad[4] else None), None, None, None
 
 
 # ------------------------------------------------------------ plain conv ----

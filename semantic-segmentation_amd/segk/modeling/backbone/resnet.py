@@ -50,8 +50,13 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         # batch-norm classes that can run a convolution, their own statistics and the ReLU as one unit do so
         unit = getattr(self.bn1, "forward_conv_relu", None)
+        slot = None
         if unit is not None and self.bn1.can_fuse_conv(self.conv1, x):
-            y = unit(self.conv1, x)
+            # x feeds conv1 and (without a projection) the shortcut: the unit behind bn3 may leave the shortcut's
+            # gradient in `slot`, and conv1's data-gradient convolution adds it (one gradient for x, no separate sum)
+            if self.downsample is None and x.requires_grad and hasattr(self.bn1, "new_grad_slot"):
+                slot = self.bn1.new_grad_slot()
+            y = unit(self.conv1, x, slot) if slot is not None else unit(self.conv1, x)
         else:
             y = _bn_relu(self.bn1, self.relu, self.conv1(x))
         unit = getattr(self.bn2, "forward_conv_relu", None)
@@ -64,7 +69,7 @@ class Bottleneck(nn.Module):
             # (x receives two gradients, from this path and from conv1: their sum does not depend on the order)
             res = x if self.downsample is None else self.downsample(x)
             if self.bn3.can_fuse_conv_residual(self.conv3, y, res):
-                return unit(self.conv3, y, res)
+                return unit(self.conv3, y, res, slot) if slot is not None else unit(self.conv3, y, res)
             y = self.conv3(y)
         else:
             y = self.conv3(y)
@@ -73,7 +78,7 @@ class Bottleneck(nn.Module):
             res = x if self.downsample is None else self.downsample(x)
         fused = getattr(self.bn3, "forward_add_relu", None)
         if fused is not None and self.bn3.can_fuse_residual(y, res):
-            return fused(y, res)
+            return fused(y, res, slot) if slot is not None else fused(y, res)
         y = self.bn3(y)
         y += res
         return self.relu(y)

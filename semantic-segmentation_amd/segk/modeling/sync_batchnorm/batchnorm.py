@@ -51,13 +51,20 @@ class _SynchronizedBatchNorm(_BatchNorm):
             raise ValueError("expected %d channels, got %d" % (self.num_features, input.shape[1]))
         return SF.SyncBNFunction.apply(input, self.weight, self.bias, self, True)
 
-    def forward_add_relu(self, input, residual):
+    def forward_add_relu(self, input, residual, grad_slot=None):
         """relu(self(input) + residual) in one pass: the tail of a bottleneck block.  Needs channels_last tensors of
-        one dtype; callers fall back to the separate operations otherwise."""
+        one dtype; callers fall back to the separate operations otherwise.  grad_slot: see new_grad_slot."""
         self._check_input_dim(input)
         if input.shape[1] != self.num_features:
             raise ValueError("expected %d channels, got %d" % (self.num_features, input.shape[1]))
-        return SF.SyncBNFunction.apply(input, self.weight, self.bias, self, True, residual)
+        return SF.SyncBNFunction.apply(input, self.weight, self.bias, self, True, residual, grad_slot)
+
+    @staticmethod
+    def new_grad_slot():
+        """For a block whose input x feeds both a forward_conv_relu unit and the shortcut of a forward_add_relu /
+        forward_conv_add_relu unit: pass the same slot to both and the shortcut's gradient is added inside the first
+        unit's data-gradient convolution instead of by a separate addition (segk.functional.GradSlot)."""
+        return SF.GradSlot()
 
     @staticmethod
     def can_fuse_residual(input, residual):
@@ -82,10 +89,10 @@ class _SynchronizedBatchNorm(_BatchNorm):
             return SF.pm_view_of(input) is not None and not input.is_contiguous()
         return True
 
-    def forward_conv_relu(self, conv, input):
+    def forward_conv_relu(self, conv, input, grad_slot=None):
         """relu(self(conv(input))) as one unit on the implicit-GEMM kernels (statistics from the convolution's
         epilogue): a feeder bottleneck's conv2 -> bn2 -> relu, or its conv1 -> bn1 -> relu."""
-        return SF.ConvBNReLUFunction.apply(input, conv.weight, self.weight, self.bias, conv, self)
+        return SF.ConvBNReLUFunction.apply(input, conv.weight, self.weight, self.bias, conv, self, grad_slot)
 
     def can_fuse_conv_residual(self, conv, input, residual):
         """Whether forward_conv_add_relu(conv, input, residual) applies: a 1x1 convolution from 128 or more channels
@@ -108,10 +115,10 @@ class _SynchronizedBatchNorm(_BatchNorm):
                 and SF.pm_view_of(input) is not None and not input.is_contiguous()
                 and SF.pm_view_of(residual) is not None and not residual.is_contiguous())
 
-    def forward_conv_add_relu(self, conv, input, residual):
+    def forward_conv_add_relu(self, conv, input, residual, grad_slot=None):
         """relu(self(conv(input)) + residual) as one unit on the implicit-GEMM kernels: a feeder bottleneck's
         conv3 -> bn3 -> += residual -> relu."""
-        return SF.ConvBNAddReLUFunction.apply(input, conv.weight, self.weight, self.bias, residual, conv, self)
+        return SF.ConvBNAddReLUFunction.apply(input, conv.weight, self.weight, self.bias, residual, conv, self, grad_slot)
 
     def __data_parallel_replicate__(self, ctx, copy_id):
         raise RuntimeError("this SynchronizedBatchNorm runs one process per GPU (torch.distributed); "

@@ -398,11 +398,12 @@ def weight_usable_in_place(w, R, Cout):
 
 
 def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=False, true_ck=None, batch=1,
-             dil_step=0, out_batch=0):
+             dil_step=0, out_batch=0, addend=None):
     """segs: list of (in_view [M, >=Ck], packed_w [taps, Cout, Ck], R, dil); instead of a packed operand a segment
     may carry the nn.Conv2d weight itself when it is channels_last [Cout, Cin, R, R] of the operand dtype with Cin a
     multiple of 32 (used in place).  Writes `out` ([M, Cout'] view, Cout' >= Cout rounded up to 4).  Returns the [rows, 2, Cout] statistic partials when want_stats.
-    true_ck: un-padded contracted channel counts per segment (only used for FLOP accounting)."""
+    true_ck: un-padded contracted channel counts per segment (only used for FLOP accounting).
+    addend: pixel-major view [M, >=Cout] of out's dtype: out = round(conv) + addend (see conv_addend_ok)."""
     M = N * H * W
     timer_ck = true_ck if true_ck is not None else [(w.shape[1] if w.dim() == 4 and batch <= 1 else w.shape[-1])
                                                     for _, w, _, _ in segs]
@@ -446,6 +447,14 @@ def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=Fals
             raise ValueError("%s must be contiguous float32 with %d elements" % (name, n))
     a.bias = bias.data_ptr() if bias is not None else None
     a.img_bias = img_bias.data_ptr() if img_bias is not None else None
+    if addend is not None:
+        _dev(addend)
+        ald, ac = _pm(addend)
+        if addend.dtype != out.dtype or addend.shape[0] != M or ac < Cout:
+            raise ValueError("the addend is a pixel-major view of the output's dtype with at least Cout channels")
+        a.addend, a.addend_ld = addend.data_ptr(), ald
+    else:
+        a.addend, a.addend_ld = None, 0
     if batch > 1:
         if len(segs) != 1 or bias is not None or img_bias is not None:
             raise ValueError("a batched convolution has one segment and no bias")
@@ -470,6 +479,17 @@ def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=Fals
                 inb += f * inbounds_fraction(H, W, segs[i][2], segs[i][3] + b * dil_step)
         TIMER.stop("conv_fwd_kernel", fl, t0, inbounds=inb)
     return stats
+
+
+def conv_addend_ok(segs, Cout, out_dtype, addend):
+    """Whether conv_fwd(..., addend=addend) can add `addend` in its epilogue: bf16 operands whose contracted rows are
+    multiples of 128 bytes (the ring tiles), Cout a multiple of 128, addend rows aligned for the output's stores."""
+    if addend is None or addend.dim() != 2 or addend.stride(1) != 1 or addend.dtype != out_dtype:
+        return False
+    es = addend.element_size()
+    if Cout % 128 or addend.shape[1] < Cout or addend.data_ptr() % (4 * es) or (addend.stride(0) * es) % (4 * es):
+        return False
+    return all(x.dtype == torch.bfloat16 and (w.shape[1] if w.dim() == 4 else w.shape[-1]) % 64 == 0 for x, w, _, _ in segs)
 
 
 def _ring_parts(chunks, Cin, Cout, R, cus=256):

@@ -223,3 +223,45 @@ def test_unit_1x1_residual_backward_takes_unaligned_gradients():
     assert wide[:, 4:].data_ptr() % 16 != 0
     for a, b in zip(grads["aligned"], grads["slice"]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("planes,hw", [(256, 9), (64, 17)])
+def test_bottleneck_shortcut_gradient_added_in_the_data_gradient(planes, hw):
+    """An identity bottleneck (newmodeling/backbone/resnet101_2.py:31-51): its input feeds conv1 and the shortcut.  With
+    the gradient slot the shortcut's gradient is added in the epilogue of conv1's data-gradient convolution; without
+    it autograd adds the two tensors.  Same bits in the input gradient and in every parameter gradient.  (256 planes:
+    all three units on the HIP kernels; 64 planes, ResNet layer 1: conv1 on them, the shortcut's gradient comes out of
+    the stand-alone batch norm with residual.)"""
+    from segk.modeling.backbone.resnet import Bottleneck
+    from segk.modeling.sync_batchnorm import SynchronizedBatchNorm2d
+    dev = "cuda"
+    torch.manual_seed(planes)
+    blk = Bottleneck(planes * 4, planes, 1, 1, None, SynchronizedBatchNorm2d).to(dev).to(memory_format=torch.channels_last)
+    for m in blk.modules():
+        if isinstance(m, nn.Conv2d):
+            m.weight.data = m.weight.data.to(torch.bfloat16)
+    x0 = torch.randn(2, planes * 4, hw, hw + 2, device=dev).relu().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn_like(x0)
+    seen = []
+
+    def run(use_slot):
+        import contextlib
+        from unittest import mock
+        off = mock.patch.object(SynchronizedBatchNorm2d, "new_grad_slot", staticmethod(lambda: None))
+        with (contextlib.nullcontext() if use_slot else off):
+            blk.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                y = blk(x)
+            y.backward(gy)
+        return [x.grad.clone(), y.detach().clone()] + [p.grad.clone() for p in blk.parameters()]
+
+    # (the 64-plane block's 3x3 and its last 1x1 run on MIOpen, whose default gradients differ from run to run)
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    try:
+        with_slot, without = run(True), run(False)
+    finally:
+        torch.use_deterministic_algorithms(False)
+    for a, b in zip(with_slot, without):
+        assert torch.equal(a, b)
+    assert float(with_slot[0].float().abs().max()) > 0
