@@ -167,6 +167,27 @@ int segk_wgrad_finish_strided(const float* slabs, int splits, int R, int Cin, in
                               long long s_co, long long s_ci, long long s_tap, int Cout_true, int Cin_true,
                               segk_stream_t stream);
 
+/* Weight gradients of several convolutions of one shape in one launch.  A ResNet stage repeats one bottleneck many
+ * times (newmodeling/backbone/resnet101_2.py:100-122, `for i in range(1, blocks)`: 22 identical blocks in layer 3), and
+ * on the 33 x 33 maps of that stage one weight gradient alone has too few tiles for the chip: it has to be cut into many
+ * pixel parts, each of which writes a whole fp32 copy of the gradient.  Together the same launch is filled with a
+ * fraction of the parts per convolution.  conv.in / conv.dout are ignored; conv.slabs holds
+ * [groups][splits][R*R][Cin][Cout] floats.  bf16 operands and Cout a multiple of 256 (the ring tile) only:
+ * SEGK_UNSUPPORTED_SHAPE otherwise.  The values equal segk_conv_wgrad's with the same `splits`. */
+#define SEGK_WGRAD_GROUP_MAX 8
+typedef struct {
+  segk_wgrad_args conv;
+  int groups; /* 1 .. SEGK_WGRAD_GROUP_MAX */
+  const void* in[SEGK_WGRAD_GROUP_MAX];
+  const void* dout[SEGK_WGRAD_GROUP_MAX];
+} segk_wgrad_group_args;
+int segk_conv_wgrad_group(const segk_wgrad_group_args* a, segk_stream_t stream);
+/* segk_wgrad_finish_strided for the slabs of segk_conv_wgrad_group: dw[g] receives the gradient of convolution g;
+ * all share dtype, strides and true channel counts. */
+int segk_wgrad_finish_group(const float* slabs, int groups, int splits, int R, int Cin, int Cout, void* const* dw,
+                            int dw_dtype, long long s_co, long long s_ci, long long s_tap, int Cout_true,
+                            int Cin_true, segk_stream_t stream);
+
 /* ---- batched matrix products (attention: modeling/damm_cam_pam.py) --------------------------- */
 typedef struct {
   const void* A;     /* [batch][M][lda] */

@@ -843,6 +843,11 @@ struct WgradDev {
   long long per_split;  // pixels per split (multiple of the pixel chunk)
   float* slabs;
   long long in_batch_b, dout_batch_b;  // batched GEMM use (blockIdx.y); 0 for convolutions
+  // groups > 0 (ring tile only): blockIdx.y names one of several convolutions of the same shape, each with its own
+  // operands; its slabs follow those of the convolution before it
+  int groups;
+  const char* in_g[SEGK_WGRAD_GROUP_MAX];
+  const char* dout_g[SEGK_WGRAD_GROUP_MAX];
 };
 
 // Tile = [BP pixels][128 channels]; row bytes RB = 128*sizeof(T).
@@ -2276,8 +2281,9 @@ __global__ __launch_bounds__(64 * (4 + MW), (4 + MW) / 4) void conv_wgrad_ring_k
       doff[i] = lrow[i] * (int)p.dout_ld_b + csrc * 16;
       xoff[i] = lrow[i] * (int)p.in_ld_b + csrc * 16;
     }
-    const char* dbase = p.dout + bz * p.dout_batch_b + (size_t)co0 * 2 + pbeg * p.dout_ld_b;
-    const char* xbase = p.in + bz * p.in_batch_b + (size_t)ci0 * 2 + (pbeg + (long long)dy * p.W + dx) * p.in_ld_b;
+    const char* dbase = (p.groups > 0 ? p.dout_g[bz] : p.dout + bz * p.dout_batch_b) + (size_t)co0 * 2 + pbeg * p.dout_ld_b;
+    const char* xbase = (p.groups > 0 ? p.in_g[bz] : p.in + bz * p.in_batch_b) + (size_t)ci0 * 2 +
+                        (pbeg + (long long)dy * p.W + dx) * p.in_ld_b;
     const long long dstep = (long long)BP * p.dout_ld_b, xstep = (long long)BP * p.in_ld_b;
     int fill = 0, issued = 0, handed = 0;
     auto wait_behind = [&](int steps) {   // the immediate has to be a literal
@@ -2858,24 +2864,24 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
   return SEGK_OK;
 }
 
-extern "C" int segk_conv_wgrad(const segk_wgrad_args* a, segk_stream_t stream) {
-  SEGK_REQUIRE(a && a->in && a->dout && a->slabs, "wgrad: null pointer");
-  SEGK_REQUIRE(valid_dtype(a->dtype), "wgrad: bad dtype");
-  SEGK_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0, "wgrad: bad shape");
-  SEGK_REQUIRE(a->Cin > 0 && a->Cin % 32 == 0 && a->Cin <= a->in_ld, "wgrad: Cin=%d must be a multiple of 32 and <= ld=%d",
+// shape and stride checks shared by the single and the grouped weight gradient; fills everything but the operands
+static int wgrad_problem(const segk_wgrad_args* a, WgradDev& d, const char* name) {
+  SEGK_REQUIRE(valid_dtype(a->dtype), "%s: bad dtype", name);
+  SEGK_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0, "%s: bad shape", name);
+  SEGK_REQUIRE(a->Cin > 0 && a->Cin % 32 == 0 && a->Cin <= a->in_ld, "%s: Cin=%d must be a multiple of 32 and <= ld=%d", name,
                a->Cin, a->in_ld);
-  SEGK_REQUIRE(a->Cout > 0 && a->Cout % 16 == 0 && a->Cout <= a->dout_ld, "wgrad: Cout=%d must be a multiple of 16 and <= ld=%d",
-               a->Cout, a->dout_ld);
-  SEGK_REQUIRE((a->R == 1 || a->R == 3) && a->dil >= 1 && a->splits >= 1, "wgrad: R=%d dil=%d splits=%d", a->R, a->dil,
+  SEGK_REQUIRE(a->Cout > 0 && a->Cout % 16 == 0 && a->Cout <= a->dout_ld, "%s: Cout=%d must be a multiple of 16 and <= ld=%d",
+               name, a->Cout, a->dout_ld);
+  SEGK_REQUIRE((a->R == 1 || a->R == 3) && a->dil >= 1 && a->splits >= 1, "%s: R=%d dil=%d splits=%d", name, a->R, a->dil,
                a->splits);
   const int es = dtype_size(a->dtype);
-  SEGK_REQUIRE(aligned16(a->in) && aligned16(a->dout) && aligned16(a->slabs) && ((long long)a->in_ld * es) % 16 == 0 &&
-                   ((long long)a->dout_ld * es) % 16 == 0,
-               "wgrad: operands must be 16-byte aligned with 16-byte multiple row strides");
-  WgradDev d;
+  SEGK_REQUIRE(a->slabs && aligned16(a->slabs) && ((long long)a->in_ld * es) % 16 == 0 && ((long long)a->dout_ld * es) % 16 == 0,
+               "%s: slabs must be 16-byte aligned and row strides multiples of 16 bytes", name);
+  SEGK_REQUIRE(a->tile == 0 || a->tile == 128 || a->tile == 256 || a->tile == 384, "%s: tile=%d (0, 128, 256 or 384)", name,
+               a->tile);
   d.H = a->H; d.W = a->W; d.HW = a->H * a->W;
   d.M = (long long)a->N * d.HW;
-  d.in = (const char*)a->in; d.dout = (const char*)a->dout;
+  d.in = nullptr; d.dout = nullptr;
   d.in_ld_b = (long long)a->in_ld * es; d.dout_ld_b = (long long)a->dout_ld * es;
   d.Cin = a->Cin; d.Cout = a->Cout; d.R = a->R; d.dil = a->dil; d.splits = a->splits;
   const int bp = a->dtype == SEGK_BF16 ? WgFrag<bf16_t>::BP : WgFrag<float>::BP;
@@ -2884,12 +2890,48 @@ extern "C" int segk_conv_wgrad(const segk_wgrad_args* a, segk_stream_t stream) {
   d.per_split = per;
   d.slabs = a->slabs;
   d.in_batch_b = 0; d.dout_batch_b = 0;
+  d.groups = 0;
+  for (int g = 0; g < SEGK_WGRAD_GROUP_MAX; ++g) d.in_g[g] = d.dout_g[g] = nullptr;
+  return SEGK_OK;
+}
+
+extern "C" int segk_conv_wgrad(const segk_wgrad_args* a, segk_stream_t stream) {
+  SEGK_REQUIRE(a && a->in && a->dout && a->slabs, "wgrad: null pointer");
+  SEGK_REQUIRE(aligned16(a->in) && aligned16(a->dout), "wgrad: operands must be 16-byte aligned");
+  WgradDev d;
+  int rc = wgrad_problem(a, d, "wgrad");
+  if (rc != SEGK_OK) return rc;
+  d.in = (const char*)a->in; d.dout = (const char*)a->dout;
   hipStream_t st = (hipStream_t)stream;
-  SEGK_REQUIRE(a->tile == 0 || a->tile == 128 || a->tile == 256 || a->tile == 384, "wgrad: tile=%d (0, 128, 256 or 384)", a->tile);
-  int rc = a->dtype == SEGK_BF16 ? launch_wgrad<bf16_t>(d, 1, st, "conv_wgrad", a->tile)
-                                 : launch_wgrad<float>(d, 1, st, "conv_wgrad", a->tile);
+  rc = a->dtype == SEGK_BF16 ? launch_wgrad<bf16_t>(d, 1, st, "conv_wgrad", a->tile)
+                             : launch_wgrad<float>(d, 1, st, "conv_wgrad", a->tile);
   if (rc != SEGK_OK) return rc;
   SEGK_CHECK_LAUNCH("conv_wgrad");
+  return SEGK_OK;
+}
+
+extern "C" int segk_conv_wgrad_group(const segk_wgrad_group_args* a, segk_stream_t stream) {
+  SEGK_REQUIRE(a && a->conv.slabs, "wgrad_group: null pointer");
+  SEGK_REQUIRE(a->groups >= 1 && a->groups <= SEGK_WGRAD_GROUP_MAX, "wgrad_group: groups=%d (1..%d)", a->groups,
+               SEGK_WGRAD_GROUP_MAX);
+  if (a->conv.dtype != SEGK_BF16 || a->conv.Cout % 256 != 0 || (a->conv.tile != 0 && a->conv.tile != 384)) {
+    set_error("wgrad_group: bf16 onto a multiple of 256 output channels only (the ring tile), got dtype=%d Cout=%d tile=%d",
+              a->conv.dtype, a->conv.Cout, a->conv.tile);
+    return SEGK_UNSUPPORTED_SHAPE;
+  }
+  WgradDev d;
+  int rc = wgrad_problem(&a->conv, d, "wgrad_group");
+  if (rc != SEGK_OK) return rc;
+  for (int g = 0; g < a->groups; ++g) {
+    SEGK_REQUIRE(a->in[g] && a->dout[g] && aligned16(a->in[g]) && aligned16(a->dout[g]),
+                 "wgrad_group: operands of convolution %d null or not 16-byte aligned", g);
+    d.in_g[g] = (const char*)a->in[g];
+    d.dout_g[g] = (const char*)a->dout[g];
+  }
+  d.groups = a->groups;
+  rc = launch_wgrad_ring(d, a->groups, (hipStream_t)stream, "conv_wgrad_group");
+  if (rc != SEGK_OK) return rc;
+  SEGK_CHECK_LAUNCH("conv_wgrad_group");
   return SEGK_OK;
 }
 
@@ -2992,6 +3034,8 @@ extern "C" int segk_gemm_tn(const segk_gemm_tn_args* a, segk_stream_t stream) {
   d.per_split = per;
   d.slabs = a->slabs;
   d.in_batch_b = a->a_batch * es; d.dout_batch_b = a->b_batch * es;
+  d.groups = 0;
+  for (int g = 0; g < SEGK_WGRAD_GROUP_MAX; ++g) d.in_g[g] = d.dout_g[g] = nullptr;
   hipStream_t st = (hipStream_t)stream;
   int rc = a->dtype == SEGK_BF16 ? launch_wgrad<bf16_t>(d, a->batch, st, "gemm_tn") : launch_wgrad<float>(d, a->batch, st, "gemm_tn");
   if (rc != SEGK_OK) return rc;

@@ -171,14 +171,21 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const segk_pack_item*
 #undef SEGK_PACK
 }
 
-// dw[co][ci][tap] = sum_s slabs[s][tap][ci][co]
+// the gradient tensors of the convolutions of one launch (one for a single weight gradient)
+struct FinishGroup {
+  void* dw[SEGK_WGRAD_GROUP_MAX];
+};
+
+// dw[g][co][ci][tap] = sum_s slabs[g][s][tap][ci][co]; blockIdx.z = g * taps + tap
 template <typename TD>
 __global__ void wgrad_finish_kernel(const float* __restrict__ slabs, int splits, int taps, int Cin, int Cout,
-                                    TD* __restrict__ dw, long long s_co, long long s_ci, long long s_tap,
+                                    const FinishGroup group, long long s_co, long long s_ci, long long s_tap,
                                     int Cout_true, int Cin_true) {
   // tile transpose over (ci, co) for one tap: reads run along co, writes along (ci, tap)
   __shared__ float tile[32][33];
-  const int tap = blockIdx.z;
+  const int gi = blockIdx.z / taps, tap = blockIdx.z - gi * taps;
+  TD* __restrict__ dw = (TD*)group.dw[gi];
+  slabs += (size_t)gi * splits * taps * Cin * Cout;
   const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const size_t slab = (size_t)taps * Cin * Cout;
@@ -214,11 +221,13 @@ __global__ void wgrad_finish_kernel(const float* __restrict__ slabs, int splits,
 // added in row order: a fixed order, and eight times the loads in flight of the serial walk above.
 template <typename TD>
 __global__ __launch_bounds__(256) void wgrad_finish_tree_kernel(const float* __restrict__ slabs, int splits, int taps,
-                                                                int Cin, int Cout, TD* __restrict__ dw, long long s_co,
+                                                                int Cin, int Cout, const FinishGroup group, long long s_co,
                                                                 long long s_ci, long long s_tap, int Cout_true,
                                                                 int Cin_true) {
   __shared__ float part[8][8][33];
-  const int tap = blockIdx.z;
+  const int gi = blockIdx.z / taps, tap = blockIdx.z - gi * taps;
+  TD* __restrict__ dw = (TD*)group.dw[gi];
+  slabs += (size_t)gi * splits * taps * Cin * Cout;
   const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 8;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const size_t slab = (size_t)taps * Cin * Cout;
@@ -348,36 +357,52 @@ extern "C" int segk_pack_weight(const float* w, void* dst, int dst_dtype, int Co
                                   stream);
 }
 
-extern "C" int segk_wgrad_finish_strided(const float* slabs, int splits, int R, int Cin, int Cout, void* dw,
-                                         int dw_dtype, long long s_co, long long s_ci, long long s_tap, int Cout_true,
-                                         int Cin_true, segk_stream_t stream) {
+extern "C" int segk_wgrad_finish_group(const float* slabs, int groups, int splits, int R, int Cin, int Cout,
+                                       void* const* dw, int dw_dtype, long long s_co, long long s_ci, long long s_tap,
+                                       int Cout_true, int Cin_true, segk_stream_t stream) {
   SEGK_REQUIRE(slabs && dw && valid_dtype(dw_dtype), "wgrad_finish: null pointer or bad dtype");
+  SEGK_REQUIRE(groups >= 1 && groups <= SEGK_WGRAD_GROUP_MAX, "wgrad_finish: groups=%d (1..%d)", groups, SEGK_WGRAD_GROUP_MAX);
   SEGK_REQUIRE(splits >= 1 && (R == 1 || R == 3) && Cin > 0 && Cout > 0 && Cout_true > 0 && Cout_true <= Cout &&
                    Cin_true > 0 && Cin_true <= Cin,
                "wgrad_finish: bad shape splits=%d R=%d Cin=%d Cout=%d (%d,%d)", splits, R, Cin, Cout, Cout_true,
                Cin_true);
   SEGK_REQUIRE(s_co > 0 && s_ci > 0 && s_tap > 0, "wgrad_finish: strides must be positive");
+  FinishGroup group;
+  for (int g = 0; g < SEGK_WGRAD_GROUP_MAX; ++g) {
+    group.dw[g] = g < groups ? dw[g] : nullptr;
+    SEGK_REQUIRE(g >= groups || dw[g], "wgrad_finish: gradient %d is null", g);
+  }
   hipStream_t st = (hipStream_t)stream;
+  const unsigned gz = (unsigned)(R * R * groups);
   if (splits >= 32 && (long long)R * R * Cin * Cout <= (1ll << 18)) {
-    dim3 tgrid(ceil_div(Cout, 32), ceil_div(Cin, 8), R * R);
+    dim3 tgrid(ceil_div(Cout, 32), ceil_div(Cin, 8), gz);
     if (dw_dtype == SEGK_BF16)
-      wgrad_finish_tree_kernel<bf16_t><<<tgrid, 256, 0, st>>>(slabs, splits, R * R, Cin, Cout, (bf16_t*)dw, s_co, s_ci,
-                                                             s_tap, Cout_true, Cin_true);
+      wgrad_finish_tree_kernel<bf16_t><<<tgrid, 256, 0, st>>>(slabs, splits, R * R, Cin, Cout, group, s_co, s_ci, s_tap,
+                                                             Cout_true, Cin_true);
     else
-      wgrad_finish_tree_kernel<float><<<tgrid, 256, 0, st>>>(slabs, splits, R * R, Cin, Cout, (float*)dw, s_co, s_ci,
-                                                            s_tap, Cout_true, Cin_true);
+      wgrad_finish_tree_kernel<float><<<tgrid, 256, 0, st>>>(slabs, splits, R * R, Cin, Cout, group, s_co, s_ci, s_tap,
+                                                            Cout_true, Cin_true);
     SEGK_CHECK_LAUNCH("wgrad_finish");
     return SEGK_OK;
   }
-  dim3 grid(ceil_div(Cout, 32), ceil_div(Cin, 32), R * R);
+  dim3 grid(ceil_div(Cout, 32), ceil_div(Cin, 32), gz);
   if (dw_dtype == SEGK_BF16)
-    wgrad_finish_kernel<bf16_t><<<grid, 256, 0, st>>>(slabs, splits, R * R, Cin, Cout, (bf16_t*)dw, s_co, s_ci, s_tap,
-                                                      Cout_true, Cin_true);
+    wgrad_finish_kernel<bf16_t><<<grid, 256, 0, st>>>(slabs, splits, R * R, Cin, Cout, group, s_co, s_ci, s_tap, Cout_true,
+                                                      Cin_true);
   else
-    wgrad_finish_kernel<float><<<grid, 256, 0, st>>>(slabs, splits, R * R, Cin, Cout, (float*)dw, s_co, s_ci, s_tap,
-                                                     Cout_true, Cin_true);
+    wgrad_finish_kernel<float><<<grid, 256, 0, st>>>(slabs, splits, R * R, Cin, Cout, group, s_co, s_ci, s_tap, Cout_true,
+                                                     Cin_true);
   SEGK_CHECK_LAUNCH("wgrad_finish");
   return SEGK_OK;
+}
+
+extern "C" int segk_wgrad_finish_strided(const float* slabs, int splits, int R, int Cin, int Cout, void* dw,
+                                         int dw_dtype, long long s_co, long long s_ci, long long s_tap, int Cout_true,
+                                         int Cin_true, segk_stream_t stream) {
+  SEGK_REQUIRE(dw, "wgrad_finish: null pointer");
+  void* one[1] = {dw};
+  return segk_wgrad_finish_group(slabs, 1, splits, R, Cin, Cout, one, dw_dtype, s_co, s_ci, s_tap, Cout_true, Cin_true,
+                                 stream);
 }
 
 extern "C" int segk_wgrad_finish(const float* slabs, int splits, int R, int Cin, int Cout, float* dw, int Cout_true,

@@ -36,6 +36,14 @@ class WgradArgs(ctypes.Structure):
                 ("dil", c_int), ("splits", c_int), ("slabs", c_void_p), ("tile", c_int)]
 
 
+WGRAD_GROUP_MAX = 8
+
+
+class WgradGroupArgs(ctypes.Structure):
+    _fields_ = [("conv", WgradArgs), ("groups", c_int), ("inp", c_void_p * WGRAD_GROUP_MAX),
+                ("dout", c_void_p * WGRAD_GROUP_MAX)]
+
+
 class GemmTerm(ctypes.Structure):
     _fields_ = [("A", c_void_p), ("a_batch", c_ll), ("lda", c_int), ("B", c_void_p), ("b_batch", c_ll), ("ldb", c_int),
                 ("K", c_int)]
@@ -69,6 +77,9 @@ SIGNATURES = {
     "segk_wgrad_finish": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
     "segk_wgrad_finish_strided": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_ll, c_ll, c_ll, c_int, c_int,
                                   c_void_p],
+    "segk_conv_wgrad_group": [ctypes.POINTER(WgradGroupArgs), c_void_p],
+    "segk_wgrad_finish_group": [c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p), c_int, c_ll, c_ll,
+                                c_ll, c_int, c_int, c_void_p],
     "segk_gemm_nt": [ctypes.POINTER(GemmArgs), c_void_p],
     "segk_gemm_tn": [ctypes.POINTER(GemmTnArgs), c_void_p],
     "segk_gemm_tn_finish": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_ll, c_int, c_int, c_int, c_void_p],

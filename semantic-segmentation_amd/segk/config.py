@@ -6,6 +6,7 @@ import torch
 import os
 
 _state = {"compute_dtype": torch.float32, "legacy_clamp_eps": False, "feeder_conv": "auto", "overlap_wgrad": False,
+          "group_wgrad": os.environ.get("SEGK_GROUP_WGRAD", "1") != "0",
           # debug switches (each costs a host synchronisation or an extra pass where it acts)
           "debug_packs": os.environ.get("SEGK_DEBUG_PACKS", "") == "1",
           "debug_labels": os.environ.get("SEGK_DEBUG_LABELS", "") == "1",
@@ -97,6 +98,29 @@ def overlap_wgrad_as(flag):
         yield
     finally:
         _state["overlap_wgrad"] = old
+
+
+def set_group_wgrad(flag):
+    """True (default; SEGK_GROUP_WGRAD=0 turns it off): with overlap_wgrad, weight gradients of one shape that a single
+    launch cannot fill the chip with (the repeated bottlenecks of a ResNet stage on 33 x 33 maps) are collected, up to
+    eight at a time, and computed by one launch on the second stream.  A gradient waits at most until eight further
+    weight gradients have passed without one of its shape, or until the end of the backward pass.  The values differ in
+    the last bits from the ungrouped ones (the pixel range is cut into fewer parts)."""
+    _state["group_wgrad"] = bool(flag)
+
+
+def group_wgrad():
+    return _state["group_wgrad"]
+
+
+@contextlib.contextmanager
+def group_wgrad_as(flag):
+    old = _state["group_wgrad"]
+    set_group_wgrad(flag)
+    try:
+        yield
+    finally:
+        _state["group_wgrad"] = old
 
 
 # ---- debug switches ------------------------------------------------------------------------------------------

@@ -205,6 +205,16 @@ def unit_finish(x, raw, stats, weight, R, dil, geom, spec, gamma, beta, out, rel
 # ---- weight gradients beside the data-gradient chain (config.set_overlap_wgrad) -------------------------------
 _SIDE_STREAMS = {}   # device index -> the second stream
 _PENDING = []        # (weight, dW, main stream, side stream, tensors the side stream reads, backward pass id)
+_GROUPS = {}         # shape key -> _Group: gradients of one shape waiting for a launch together (config.group_wgrad)
+_CLOCK = [0, None]   # [weight_grad calls on the deferred path, backward pass id of everything queued]
+GROUP_IDLE = 8       # a group is launched once this many deferred gradients have passed without one of its shape
+
+
+class _Group:
+    __slots__ = ("items", "last", "args")
+
+    def __init__(self, args):
+        self.items, self.last, self.args = [], 0, args
 
 
 def _backward_pass_id():
@@ -213,9 +223,41 @@ def _backward_pass_id():
     return f() if f is not None else -1
 
 
+def _launch_deferred(entries, args, pass_id):
+    """Start the weight gradients of `entries` = [(weight, x, dy, like, main, side)] (one shape, one device) on the
+    second stream, as one launch when there are several, and queue them for the join."""
+    N, H, W, R, dil, Cout, Cin = args
+    main, side = entries[0][4], entries[0][5]
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        if len(entries) == 1:
+            weight, x, dy, like = entries[0][:4]
+            dws = [ops.conv_wgrad(x, dy, N, H, W, R, dil, Cout, Cin, like=like)]
+        else:
+            dws = ops.conv_wgrad_group([e[1] for e in entries], [e[2] for e in entries], N, H, W, R, dil, Cout, Cin,
+                                       like=entries[0][3])
+        for i, (weight, x, dy, like, _, _) in enumerate(entries):
+            if like is None and (dws[i].dtype != weight.dtype or dws[i].stride() != weight.stride()):
+                dws[i] = torch.empty_like(weight).copy_(dws[i])   # what autograd would have done on accumulation
+    # x and dy stay referenced until the join, so the allocator cannot hand their memory to later launches of the
+    # main stream while the second stream still reads them
+    for (weight, x, dy, like, _, _), dw in zip(entries, dws):
+        _PENDING.append((weight, dw, main, side, (x, dy), pass_id))
+
+
+def _flush_groups(only_idle):
+    for key in list(_GROUPS):
+        g = _GROUPS[key]
+        if only_idle and _CLOCK[0] - g.last < GROUP_IDLE and len(g.items) < ops.WGRAD_GROUP_MAX:
+            continue
+        del _GROUPS[key]
+        _launch_deferred(g.items, g.args, _CLOCK[1])
+
+
 def _join_weight_grads():
-    """End-of-backward callback: the launching stream waits for the second one, then every deferred gradient is
-    stored where autograd's accumulation node would have put it."""
+    """End-of-backward callback: the groups still waiting are launched, the launching stream waits for the second one,
+    then every deferred gradient is stored where autograd's accumulation node would have put it."""
+    _flush_groups(only_idle=False)
     pending = list(_PENDING)
     del _PENDING[:]
     joined = set()
@@ -232,8 +274,9 @@ def _join_weight_grads():
 
 
 def weight_grad(weight, x, dy, N, H, W, R, dil, Cout, Cin, like=None):
-    """dW of one convolution.  Returns the gradient, or None when it was started on the second stream and will be
-    stored in weight.grad at the end of the running backward pass (config.overlap_wgrad)."""
+    """dW of one convolution.  Returns the gradient, or None when it was started (or queued for a launch together with
+    others of its shape) on the second stream and will be stored in weight.grad at the end of the running backward
+    pass (config.overlap_wgrad, config.group_wgrad)."""
     deferred = (config.overlap_wgrad() and not parallel.is_distributed() and isinstance(weight, torch.Tensor)
                 and weight.is_leaf and weight.requires_grad and x.is_cuda)
     if not deferred:
@@ -242,22 +285,31 @@ def weight_grad(weight, x, dy, N, H, W, R, dil, Cout, Cin, like=None):
     side = _SIDE_STREAMS.get(x.device.index)
     if side is None:
         side = _SIDE_STREAMS[x.device.index] = torch.cuda.Stream(device=x.device)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        dw = ops.conv_wgrad(x, dy, N, H, W, R, dil, Cout, Cin, like=like)
-        if like is None and (dw.dtype != weight.dtype or dw.stride() != weight.stride()):
-            dw = torch.empty_like(weight).copy_(dw)   # what autograd would have done on accumulation
-    # one callback per deferred gradient: the first to run joins and stores them all, the others find nothing left
-    # (a callback queued only "when the list was empty" would be lost for good after a backward pass that raised)
-    torch.autograd.Variable._execution_engine.queue_callback(_join_weight_grads)
-    # x and dy stay referenced until the join, so the allocator cannot hand their memory to later launches of the
-    # main stream while the second stream still reads them
     # (gradients left over from a backward pass that raised before its end-of-pass callback belong to no parameter
     # any more: they are dropped, not added to this pass's)
     pass_id = _backward_pass_id()
-    if _PENDING and _PENDING[0][5] != pass_id:
+    if _CLOCK[1] != pass_id:
         del _PENDING[:]
-    _PENDING.append((weight, dw, main, side, (x, dy), pass_id))
+        _GROUPS.clear()
+        _CLOCK[1] = pass_id
+    _CLOCK[0] += 1
+    # one callback per deferred gradient: the first to run joins and stores them all, the others find nothing left
+    # (a callback queued only "when the list was empty" would be lost for good after a backward pass that raised)
+    torch.autograd.Variable._execution_engine.queue_callback(_join_weight_grads)
+    args = (N, H, W, R, dil, Cout, Cin)
+    entry = (weight, x, dy, like, main, side)
+    if config.group_wgrad() and x.dim() == 2 and dy.dim() == 2 and x.stride(1) == 1 and dy.stride(1) == 1 \
+            and ops.wgrad_group_pays(N * H * W, x.shape[1], dy.shape[1], R, x.dtype) and dy.dtype == x.dtype:
+        layout = (weight.dtype, weight.stride()) if like is None else (like.dtype, like.stride(), "like")
+        key = (x.device.index, main.cuda_stream, args, x.shape[1], x.stride(0), dy.shape[1], dy.stride(0), layout)
+        g = _GROUPS.get(key)
+        if g is None:
+            g = _GROUPS[key] = _Group(args)
+        g.items.append(entry)
+        g.last = _CLOCK[0]
+    else:
+        _launch_deferred([entry], args, pass_id)
+    _flush_groups(only_idle=True)
     return None
 
 

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, NCHW, PM, ConvArgs, GemmArgs, GemmTnArgs, WgradArgs, call
+from ._lib import BF16, F32, NCHW, PM, ConvArgs, GemmArgs, GemmTnArgs, WgradArgs, WgradGroupArgs, call
 from ._tables import StagedTable
 
 
@@ -492,20 +492,29 @@ def conv_addend_ok(segs, Cout, out_dtype, addend):
     return all(x.dtype == torch.bfloat16 and (w.shape[1] if w.dim() == 4 else w.shape[-1]) % 64 == 0 for x, w, _, _ in segs)
 
 
-def _ring_parts(chunks, Cin, Cout, R, cus=256):
+def _ring_parts(chunks, Cin, Cout, R, cus=256, groups=1, want_time=False):
     """Parts of the pixel range for the ring tile (256 x 128 of one tap per workgroup, one workgroup per CU).  A
     cost model in microseconds fitted to kernel durations on MI355X: workgroups run in rounds of one per CU, a
     64-pixel chunk takes 0.9 us, a workgroup has 8 us of fixed cost (prologue, 128 KB slab store), and every part
-    adds a whole fp32 copy of the gradient that the fixed-order sum reads back (0.3 us per MB)."""
-    tiles = (Cout // 256) * ((Cin + 127) // 128) * R * R
-    slab_mb = R * R * Cin * Cout * 4 / 1e6
+    adds a whole fp32 copy of the gradient that the fixed-order sum reads back (0.3 us per MB).  groups: that many
+    convolutions of this shape in one launch (conv_wgrad_group).  want_time: -> (parts, modelled microseconds)."""
+    tiles = (Cout // 256) * ((Cin + 127) // 128) * R * R * groups
+    slab_mb = R * R * Cin * Cout * 4 / 1e6 * groups
     best, best_t = 1, None
     for sp in range(1, max(1, min(SPLIT_CAP, chunks // 8)) + 1):
         rounds = (tiles * sp + cus - 1) // cus
         t = rounds * (0.9 * ((chunks + sp - 1) // sp) + 8.0) + 3.0 + sp * slab_mb * 0.3
         if best_t is None or t < best_t:
             best, best_t = sp, t
-    return best
+    return (best, best_t) if want_time else best
+
+
+def wgrad_group_pays(M, Cin, Cout, R, dtype):
+    """Whether weight gradients of this shape are worth collecting for conv_wgrad_group: the ring tile takes them and a
+    single one has to be cut into four or more parts to fill the chip."""
+    if dtype != torch.bfloat16 or Cout % 256:
+        return False
+    return _ring_parts(max(1, (M + 63) // 64), Cin, Cout, R) >= 4
 
 
 def wgrad_plan(M, Cin, Cout, R, dtype, ring=True):
@@ -542,6 +551,7 @@ def wgrad_plan(M, Cin, Cout, R, dtype, ring=True):
 
 
 SPLIT_CAP = 64
+WGRAD_GROUP_MAX = _lib.WGRAD_GROUP_MAX
 SPLIT_CAP_SMALL = 384
 SLAB_BUDGET = 32 << 20
 
@@ -584,6 +594,52 @@ def conv_wgrad(x, dout, N, H, W, R, dil, Cout_true, Cin_true, splits=None, like=
         fl = 2.0 * M * Cout_true * Cin_true * R * R
         TIMER.stop("conv_wgrad_kernel", fl, t0, inbounds=fl * inbounds_fraction(H, W, R, dil))
     return dw
+
+
+def conv_wgrad_group(xs, douts, N, H, W, R, dil, Cout_true, Cin_true, like=None, splits=None):
+    """Weight gradients of len(xs) <= WGRAD_GROUP_MAX convolutions of one shape in one launch (plus one launch for the
+    fixed-order sums): -> list of gradients as conv_wgrad returns them.  bf16 operands whose padded output channels
+    are a multiple of 256; every x (and every dout) has the same shape and row stride."""
+    G = len(xs)
+    if not 1 <= G <= _lib.WGRAD_GROUP_MAX or len(douts) != G:
+        raise ValueError("1..%d convolutions per group, got %d / %d" % (_lib.WGRAD_GROUP_MAX, G, len(douts)))
+    _dev(*xs, *douts)
+    M = N * H * W
+    in_ld, Cin = _pm(xs[0])
+    do_ld, Cout = _pm(douts[0])
+    for x, dout in zip(xs, douts):
+        if _pm(x) != (in_ld, Cin) or _pm(dout) != (do_ld, Cout) or x.shape[0] != M or dout.shape[0] != M \
+                or x.dtype != torch.bfloat16 or dout.dtype != torch.bfloat16:
+            raise ValueError("grouped weight gradients need bf16 operands of one shape and row stride")
+    if splits is None:
+        splits = _ring_parts(max(1, (M + 63) // 64), Cin, Cout, R, groups=G)
+    slabs = torch.empty((G, splits, R * R, Cin, Cout), dtype=torch.float32, device=xs[0].device)
+    a = WgradGroupArgs()
+    c = a.conv
+    c.N, c.H, c.W, c.dtype = N, H, W, _lib.BF16
+    c.in_ld, c.Cin, c.dout_ld, c.Cout = in_ld, Cin, do_ld, Cout
+    c.R, c.dil, c.splits, c.slabs, c.tile = R, dil, splits, slabs.data_ptr(), 384
+    a.groups = G
+    for g in range(G):
+        a.inp[g], a.dout[g] = xs[g].data_ptr(), douts[g].data_ptr()
+    dws = []
+    for g in range(G):
+        if like is None:
+            dws.append(torch.empty((Cout_true, Cin_true, R, R), dtype=torch.float32, device=xs[0].device))
+        else:
+            if tuple(like.shape) != (Cout_true, Cin_true, R, R):
+                raise ValueError("gradient layout model has shape %s" % (tuple(like.shape),))
+            dws.append(torch.empty_strided(like.shape, like.stride(), dtype=like.dtype, device=xs[0].device))
+    s_co, s_ci, s_tap = _weight_strides(dws[0])
+    ptrs = (ctypes.c_void_p * G)(*[d.data_ptr() for d in dws])
+    t0 = TIMER.start() if TIMER is not None else None
+    call("segk_conv_wgrad_group", ctypes.byref(a), _stream())
+    call("segk_wgrad_finish_group", _ptr(slabs), G, splits, R, Cin, Cout, ptrs, _dt(dws[0]), s_co, s_ci, s_tap,
+         Cout_true, Cin_true, _stream())
+    if t0 is not None:
+        fl = 2.0 * G * M * Cout_true * Cin_true * R * R
+        TIMER.stop("conv_wgrad_kernel", fl, t0, inbounds=fl * inbounds_fraction(H, W, R, dil))
+    return dws
 
 
 # ---------------------------------------------------- batched matrix products ----

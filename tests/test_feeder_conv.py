@@ -265,3 +265,69 @@ def test_bottleneck_shortcut_gradient_added_in_the_data_gradient(planes, hw):
     for a, b in zip(with_slot, without):
         assert torch.equal(a, b)
     assert float(with_slot[0].float().abs().max()) > 0
+
+
+def test_repeated_bottlenecks_weight_gradients_in_groups():
+    """Five identical bottlenecks on a 33 x 33 map (what ResNet-101's layer 3 repeats 22 times,
+    newmodeling/backbone/resnet101_2.py:100-122): with overlap_wgrad the weight gradients of one shape are collected
+    and computed by one launch per group.  Every gradient arrives, twice as large after a second backward pass, equal
+    to the one-by-one gradients up to the summation order of the pixel parts; data gradients are untouched (same
+    bits); a group never waits past the end of the pass, nor longer than GROUP_IDLE further gradients."""
+    from unittest import mock
+
+    from segk import config, functional as SF, ops
+    from segk.modeling.backbone.resnet import Bottleneck
+    from segk.modeling.sync_batchnorm import SynchronizedBatchNorm2d
+    dev = "cuda"
+    torch.manual_seed(3)
+    planes = 256
+    net = nn.Sequential(*[Bottleneck(planes * 4, planes, 1, 1, None, SynchronizedBatchNorm2d) for _ in range(5)])
+    net = net.to(dev).to(memory_format=torch.channels_last)
+    for m in net.modules():
+        if isinstance(m, nn.Conv2d):
+            m.weight.data = m.weight.data.to(torch.bfloat16)
+    x0 = torch.randn(2, planes * 4, 33, 33, device=dev).relu().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn_like(x0)
+    sizes = []
+
+    def rel(a, b):
+        return float((a.float() - b.float()).abs().max() / b.float().abs().max())
+
+    real_group = ops.conv_wgrad_group
+
+    def counting(xs, *a, **k):
+        sizes.append(len(xs))
+        return real_group(xs, *a, **k)
+
+    def run(group, passes=1):
+        net.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        with config.overlap_wgrad_as(True), config.group_wgrad_as(group), mock.patch.object(ops, "conv_wgrad_group", counting):
+            for _ in range(passes):
+                with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                    y = net(x)
+                y.backward(gy)
+        torch.cuda.synchronize()
+        assert not SF._GROUPS and not SF._PENDING
+        return x.grad.clone(), [p.grad.clone() for p in net.parameters()]
+
+    gx1, one_by_one = run(False)
+    assert sizes == []
+    gxg, grouped = run(True)
+    # three shapes (1024->256, 3x3 256->256, 256->1024), five members each
+    assert sorted(sizes) == [5, 5, 5], sizes
+    assert torch.equal(gx1, gxg)
+    for p, a, b in zip(net.parameters(), one_by_one, grouped):
+        assert a.shape == b.shape == p.shape and a.dtype == b.dtype and a.stride() == b.stride()
+        assert rel(b, a) < 1e-2, (tuple(p.shape), rel(b, a))   # one bf16 rounding step
+    gx2, twice = run(True, passes=2)
+    for a, b in zip(grouped, twice):
+        if a.dtype == torch.bfloat16:
+            assert rel(b, 2 * a.float()) < 1e-6
+    # the idle rule: with a short limit, groups are launched while the pass is still running
+    del sizes[:]
+    with mock.patch.object(SF, "GROUP_IDLE", 2):
+        _, early = run(True)
+    assert len(sizes) == 0 or max(sizes) < 5, sizes
+    for a, b in zip(one_by_one, early):
+        assert rel(b, a) < 1e-2

@@ -236,6 +236,48 @@ def test_conv_wgrad_ring_exact_integers(ops, case):
     assert torch.equal(ops.conv_wgrad(xfull, gfull, N, H, W, R, dil, Cout, Cin, splits=parts, tile=128), gw)
 
 
+@pytest.mark.parametrize("case", RING_WGRAD_CASES)
+@pytest.mark.parametrize("groups", [1, 3, 8])
+def test_conv_wgrad_group_exact_integers(ops, case, groups):
+    """Several convolutions of one shape in one launch (segk_conv_wgrad_group): every member gets its own gradient,
+    exact on integers for any number of parts; random data: bit for bit the single launch with the same parts."""
+    N, H, W, Cin, Cout, R, dil, parts = case
+    xs, gs, want = [], [], []
+    for k in range(groups):
+        x = T(gen.integers(10, "gw_x%s%d" % (case, k), (N, Cin, H, W), -3, 4).astype(np.float32))
+        w = torch.zeros((Cout, Cin, R, R), device=DEV, requires_grad=True)
+        y = F.conv2d(x, w, padding=dil * (R // 2), dilation=dil)
+        gy = T(gen.integers(10, "gw_g%s%d" % (case, k), tuple(y.shape), -2, 3).astype(np.float32))
+        want.append(torch.autograd.grad(y, w, gy)[0])
+        xs.append(to_pm(x, torch.bfloat16)[1])
+        gs.append(to_pm(gy, torch.bfloat16)[1])
+    for sp in (parts, None):
+        got = ops.conv_wgrad_group(xs, gs, N, H, W, R, dil, Cout, Cin, splits=sp)
+        assert len(got) == groups
+        for k in range(groups):
+            assert torch.equal(got[k], want[k]), "member %d" % k
+    # real-valued operands, a trimmed gradient in the weight's own bf16 channels_last layout
+    rx = [T(gen.normal(10, "gw_rx%s%d" % (case, k), (N, Cin, H, W))) for k in range(groups)]
+    rg = [T(gen.normal(10, "gw_rg%s%d" % (case, k), (N, Cout, H, W))) for k in range(groups)]
+    rxs = [to_pm(t, torch.bfloat16)[1] for t in rx]
+    rgs = [to_pm(t, torch.bfloat16)[1] for t in rg]
+    like = torch.empty((Cout - 3, Cin - 5, R, R), dtype=torch.bfloat16, device=DEV).to(memory_format=torch.channels_last)
+    got = ops.conv_wgrad_group(rxs, rgs, N, H, W, R, dil, Cout - 3, Cin - 5, like=like, splits=parts)
+    for k in range(groups):
+        one = ops.conv_wgrad(rxs[k], rgs[k], N, H, W, R, dil, Cout - 3, Cin - 5, like=like, splits=parts, tile=384)
+        assert got[k].stride() == like.stride() and got[k].dtype == torch.bfloat16
+        assert torch.equal(got[k], one), "member %d" % k
+
+
+def test_conv_wgrad_group_refuses_other_tiles(ops):
+    x = torch.zeros((64, 64), dtype=torch.bfloat16, device=DEV)
+    g = torch.zeros((64, 128), dtype=torch.bfloat16, device=DEV)   # 128 output channels: not the ring tile
+    with pytest.raises(RuntimeError, match="ring tile"):
+        ops.conv_wgrad_group([x, x], [g, g], 1, 8, 8, 1, 1, 128, 64, splits=1)
+    with pytest.raises(ValueError):
+        ops.conv_wgrad_group([x] * 9, [g] * 9, 1, 8, 8, 1, 1, 128, 64, splits=1)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
 def test_conv_wgrad_random_padded_input(ops, dtype, tol):
     """Decoder shape in miniature: 304 real input channels inside a 320-wide buffer."""
