@@ -215,6 +215,50 @@ __global__ void wgrad_finish_kernel(const float* __restrict__ slabs, int splits,
   }
 }
 
+// The same sum for a 3 x 3 gradient whose taps are the innermost index of dw (nn.Conv2d's own [co][ci][3][3] layout):
+// a workgroup owns 32 co x 32 ci of ALL nine taps, so that each co row of its output is one run of 288 consecutive
+// elements.  (One tap per workgroup writes every ninth element: nine visits to each memory line, by workgroups far
+// apart in time - the head's 3 x 3 gradients took 0.4 ms that way.)  Same order of additions as above.
+template <typename TD>
+__global__ __launch_bounds__(256) void wgrad_finish_taps_kernel(const float* __restrict__ slabs, int splits, int Cin,
+                                                                int Cout, const FinishGroup group, long long s_co,
+                                                                int Cout_true, int Cin_true) {
+  constexpr int TAPS = 9;
+  __shared__ float tile[TAPS][32][33];
+  const int gi = blockIdx.z;
+  TD* __restrict__ dw = (TD*)group.dw[gi];
+  const size_t slab = (size_t)TAPS * Cin * Cout;
+  slabs += (size_t)gi * splits * slab;
+  const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int tap = 0; tap < TAPS; ++tap) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ci = ci0 + ty + i * 8, co = co0 + tx;
+      float acc = 0.f;
+      if (ci < Cin && co < Cout) {
+        const float* p = slabs + ((size_t)tap * Cin + ci) * Cout + co;
+        for (int s = 0; s < splits; s += 16) {
+          float v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = s + u < splits ? p[(size_t)(s + u) * slab] : 0.f;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc += v[u];
+        }
+      }
+      tile[tap][ty + i * 8][tx] = acc;
+    }
+  }
+  __syncthreads();
+  // row co: elements (ci0 .. ci0 + 31) x 9 taps are consecutive in dw
+  for (int idx = threadIdx.x; idx < 32 * 32 * TAPS; idx += 256) {
+    const int co_l = idx / (32 * TAPS), rem = idx - co_l * (32 * TAPS);
+    const int ci_l = rem / TAPS, tap = rem - ci_l * TAPS;
+    const int co = co0 + co_l, ci = ci0 + ci_l;
+    if (co < Cout_true && ci < Cin_true) Elem<TD>::store(dw + co * s_co + (long long)ci * TAPS + tap, tile[tap][ci_l][co_l]);
+  }
+}
+
 // The same sum for small gradients cut into many parts (the 1x1 convolutions onto 48 or 21 channels at 129 x 129:
 // a 64 KB slab, hundreds of parts so that the multiplication fills the chip).  A workgroup owns 32 co x 8 ci; its
 // eight thread rows each add every eighth part (parts r, r + 8, ... in ascending order), then the eight row sums are
@@ -382,6 +426,15 @@ extern "C" int segk_wgrad_finish_group(const float* slabs, int groups, int split
     else
       wgrad_finish_tree_kernel<float><<<tgrid, 256, 0, st>>>(slabs, splits, R * R, Cin, Cout, group, s_co, s_ci, s_tap,
                                                             Cout_true, Cin_true);
+    SEGK_CHECK_LAUNCH("wgrad_finish");
+    return SEGK_OK;
+  }
+  if (R == 3 && s_tap == 1 && s_ci == 9) {
+    dim3 agrid(ceil_div(Cout, 32), ceil_div(Cin, 32), (unsigned)groups);
+    if (dw_dtype == SEGK_BF16)
+      wgrad_finish_taps_kernel<bf16_t><<<agrid, 256, 0, st>>>(slabs, splits, Cin, Cout, group, s_co, Cout_true, Cin_true);
+    else
+      wgrad_finish_taps_kernel<float><<<agrid, 256, 0, st>>>(slabs, splits, Cin, Cout, group, s_co, Cout_true, Cin_true);
     SEGK_CHECK_LAUNCH("wgrad_finish");
     return SEGK_OK;
   }

@@ -105,6 +105,46 @@ __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float (&v)[4]) {
   *reinterpret_cast<u32x2*>(p) = t;
 }
 
+// V = 4 or 8 consecutive channels of one pixel (8: one 16-byte access for bf16, two for fp32)
+template <typename T, int V>
+__device__ __forceinline__ void loadv(const T* p, float (&v)[V]);
+template <>
+__device__ __forceinline__ void loadv<float, 4>(const float* p, float (&v)[4]) { load4<float>(p, v); }
+template <>
+__device__ __forceinline__ void loadv<bf16_t, 4>(const bf16_t* p, float (&v)[4]) { load4<bf16_t>(p, v); }
+template <>
+__device__ __forceinline__ void loadv<float, 8>(const float* p, float (&v)[8]) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+  v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+template <>
+__device__ __forceinline__ void loadv<bf16_t, 8>(const bf16_t* p, float (&v)[8]) {
+  u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[2 * k] = __uint_as_float(t[k] << 16);
+    v[2 * k + 1] = __uint_as_float(t[k] & 0xffff0000u);
+  }
+}
+template <typename T, int V>
+__device__ __forceinline__ void storev(T* p, const float (&v)[V]);
+template <>
+__device__ __forceinline__ void storev<float, 4>(float* p, const float (&v)[4]) { store4<float>(p, v); }
+template <>
+__device__ __forceinline__ void storev<bf16_t, 4>(bf16_t* p, const float (&v)[4]) { store4<bf16_t>(p, v); }
+template <>
+__device__ __forceinline__ void storev<float, 8>(float* p, const float (&v)[8]) {
+  f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+  *reinterpret_cast<f32x4*>(p) = a;
+  *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+template <>
+__device__ __forceinline__ void storev<bf16_t, 8>(bf16_t* p, const float (&v)[8]) {
+  u32x4 t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+  *reinterpret_cast<u32x4*>(p) = t;
+}
+
 // Vector form for channel counts that are multiples of 8 with 16-byte aligned rows: block (chunk, n) owns 128
 // channels = 16 groups of 8 channels (one 16-byte load for bf16, two for fp32) x 16 pixel phases, four rows in flight
 // per thread; twice as many workgroups as the scalar form and 8x fewer load instructions.
@@ -155,30 +195,32 @@ __global__ __launch_bounds__(256) void pool_sum_vec_kernel(const T* __restrict__
   }
 }
 
-// pixel-major -> pixel-major; thread = (output pixel, group of 4 channels); C % 4 == 0
-template <typename TI, typename TO>
+// pixel-major -> pixel-major; thread = (output pixel, group of V channels); C % V == 0.  V = 8 where the operands
+// allow 16-byte accesses: the launch is bound by its stores (the source is a sixteenth of the output and stays in
+// the cache), and a wavefront then writes 1 KB per instruction instead of 512 bytes.
+template <typename TI, typename TO, int V>
 __global__ __launch_bounds__(256) void upsample_fwd_pm_kernel(const TI* __restrict__ in, int in_ld, int C, int Hi, int Wi,
                                                                TO* __restrict__ out, int out_ld, int Ho, int Wo,
                                                                float sy, float sx, long long total) {
-  const int cg = C >> 2;
+  const int cg = C / V;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long pix = i / cg;
-    const int c0 = (int)(i - pix * cg) * 4;
+    const int c0 = (int)(i - pix * cg) * V;
     const int ox = (int)(pix % Wo);
     const long long t = pix / Wo;
     const int oy = (int)(t % Ho);
     const long long n = t / Ho;
     const Tap ty = source_taps(oy, sy, Hi), tx = source_taps(ox, sx, Wi);
     const TI* b = in + (size_t)n * Hi * Wi * in_ld + c0;
-    float v00[4], v01[4], v10[4], v11[4], o[4];
-    load4<TI>(b + ((size_t)ty.i0 * Wi + tx.i0) * in_ld, v00);
-    load4<TI>(b + ((size_t)ty.i0 * Wi + tx.i1) * in_ld, v01);
-    load4<TI>(b + ((size_t)ty.i1 * Wi + tx.i0) * in_ld, v10);
-    load4<TI>(b + ((size_t)ty.i1 * Wi + tx.i1) * in_ld, v11);
+    float v00[V], v01[V], v10[V], v11[V], o[V];
+    loadv<TI, V>(b + ((size_t)ty.i0 * Wi + tx.i0) * in_ld, v00);
+    loadv<TI, V>(b + ((size_t)ty.i0 * Wi + tx.i1) * in_ld, v01);
+    loadv<TI, V>(b + ((size_t)ty.i1 * Wi + tx.i0) * in_ld, v10);
+    loadv<TI, V>(b + ((size_t)ty.i1 * Wi + tx.i1) * in_ld, v11);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < V; ++j)
       o[j] = ty.w0 * (tx.w0 * v00[j] + tx.w1 * v01[j]) + ty.w1 * (tx.w0 * v10[j] + tx.w1 * v11[j]);
-    store4<TO>(out + (size_t)pix * out_ld + c0, o);
+    storev<TO, V>(out + (size_t)pix * out_ld + c0, o);
   }
 }
 
@@ -220,20 +262,24 @@ __global__ __launch_bounds__(256) void upsample_fwd_nchw_kernel(const TI* __rest
   }
 }
 
-// gradient, pixel-major dout -> pixel-major din; thread = (input pixel, group of 4 channels)
-template <typename TG>
+// gradient, pixel-major dout -> pixel-major din; thread = (input pixel, group of V channels).  The output pixels that
+// read an input pixel are walked row by row, four of a row at a time: their loads are issued together, whatever
+// their weights, and added in ascending order where the weight is not zero (the order of a one-by-one walk).
+template <typename TG, int V>
 __global__ __launch_bounds__(256) void upsample_bwd_pm_kernel(const TG* __restrict__ dout, int dout_ld, int C, int Ho,
                                                                int Wo, TG* __restrict__ din, int din_ld, int cpad,
                                                                int Hi, int Wi, float sy, float sx, long long total) {
-  const int cg = cpad >> 2;
+  const int cg = cpad / V;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long pix = i / cg;
-    const int c0 = (int)(i - pix * cg) * 4;
+    const int c0 = (int)(i - pix * cg) * V;
     const int ix = (int)(pix % Wi);
     const long long t = pix / Wi;
     const int iy = (int)(t % Hi);
     const long long n = t / Hi;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
     if (c0 < C) {
       int ylo, yhi, xlo, xhi;
       reader_range(iy, sy, Ho, ylo, yhi);
@@ -242,17 +288,26 @@ __global__ __launch_bounds__(256) void upsample_bwd_pm_kernel(const TG* __restri
       for (int oy = ylo; oy <= yhi; ++oy) {
         const float wy = tap_weight(oy, iy, sy, Hi);
         if (wy == 0.f) continue;
-        for (int ox = xlo; ox <= xhi; ++ox) {
-          const float w = wy * tap_weight(ox, ix, sx, Wi);
-          if (w == 0.f) continue;
-          float g[4];
-          load4<TG>(b + ((size_t)oy * Wo + ox) * dout_ld, g);
+        const TG* row = b + (size_t)oy * Wo * dout_ld;
+        for (int ox = xlo; ox <= xhi; ox += 4) {
+          float w[4], g[4][V];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] = fmaf(w, g[j], acc[j]);
+          for (int u = 0; u < 4; ++u) {
+            const bool in = ox + u <= xhi;
+            const int x = in ? ox + u : xhi;
+            w[u] = in ? wy * tap_weight(x, ix, sx, Wi) : 0.f;
+            loadv<TG, V>(row + (size_t)x * dout_ld, g[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (w[u] != 0.f) {
+#pragma unroll
+              for (int j = 0; j < V; ++j) acc[j] = fmaf(w[u], g[u][j], acc[j]);
+            }
         }
       }
     }
-    store4<TG>(din + (size_t)pix * din_ld + c0, acc);
+    storev<TG, V>(din + (size_t)pix * din_ld + c0, acc);
   }
 }
 
@@ -596,12 +651,19 @@ extern "C" int segk_upsample_fwd(const void* in, int in_dtype, int in_ld, int N,
     SEGK_REQUIRE(C % 4 == 0 && out_ld % 4 == 0 && out_ld >= C && aligned_to(out, out_dtype == SEGK_BF16 ? 8 : 16),
                  "upsample_fwd: pixel-major destination needs C %% 4 == 0 and 4-element alignment (C=%d ld=%d)", C,
                  out_ld);
-    const long long total = (long long)N * Ho * Wo * (C / 4);
+    const bool v8 = C % 8 == 0 && in_ld % 8 == 0 && out_ld % 8 == 0 && aligned_to(in, 16) && aligned_to(out, 16);
+    const long long total = (long long)N * Ho * Wo * (C / (v8 ? 8 : 4));
     long long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-#define LAUNCH_UP(TI, TO)                                                                                         \
-  upsample_fwd_pm_kernel<TI, TO><<<(int)blocks, 256, 0, st>>>((const TI*)in, in_ld, C, Hi, Wi, (TO*)out, out_ld, Ho, \
-                                                              Wo, sy, sx, total)
+#define LAUNCH_UP(TI, TO)                                                                                             \
+  do {                                                                                                                \
+    if (v8)                                                                                                           \
+      upsample_fwd_pm_kernel<TI, TO, 8><<<(int)blocks, 256, 0, st>>>((const TI*)in, in_ld, C, Hi, Wi, (TO*)out, out_ld, \
+                                                                     Ho, Wo, sy, sx, total);                          \
+    else                                                                                                              \
+      upsample_fwd_pm_kernel<TI, TO, 4><<<(int)blocks, 256, 0, st>>>((const TI*)in, in_ld, C, Hi, Wi, (TO*)out, out_ld, \
+                                                                     Ho, Wo, sy, sx, total);                          \
+  } while (0)
     if (in_dtype == SEGK_BF16 && out_dtype == SEGK_BF16) { LAUNCH_UP(bf16_t, bf16_t); }
     else if (in_dtype == SEGK_BF16) { LAUNCH_UP(bf16_t, float); }
     else if (out_dtype == SEGK_BF16) { LAUNCH_UP(float, bf16_t); }
@@ -638,12 +700,20 @@ extern "C" int segk_upsample_bwd(const void* dout, int dout_dtype, int dout_layo
     SEGK_REQUIRE(C % 4 == 0 && din_cpad % 4 == 0 && dout_ld % 4 == 0 && din_ld % 4 == 0 && dout_ld >= C &&
                      aligned_to(dout, dout_dtype == SEGK_BF16 ? 8 : 16) && aligned_to(din, din_dtype == SEGK_BF16 ? 8 : 16),
                  "upsample_bwd: pixel-major form needs C %% 4 == 0 and 4-element alignment");
-    const long long total = (long long)N * Hi * Wi * (din_cpad / 4);
+    const bool v8 = C % 8 == 0 && din_cpad % 8 == 0 && dout_ld % 8 == 0 && din_ld % 8 == 0 && aligned_to(dout, 16) &&
+                    aligned_to(din, 16);
+    const long long total = (long long)N * Hi * Wi * (din_cpad / (v8 ? 8 : 4));
     long long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    SEGK_DISPATCH_DTYPE(dout_dtype, T,
-                        (upsample_bwd_pm_kernel<T><<<(int)blocks, 256, 0, st>>>((const T*)dout, dout_ld, C, Ho, Wo, (T*)din,
-                                                                               din_ld, din_cpad, Hi, Wi, sy, sx, total)));
+    if (v8) {
+      SEGK_DISPATCH_DTYPE(dout_dtype, T,
+                          (upsample_bwd_pm_kernel<T, 8><<<(int)blocks, 256, 0, st>>>((const T*)dout, dout_ld, C, Ho, Wo, (T*)din,
+                                                                                    din_ld, din_cpad, Hi, Wi, sy, sx, total)));
+    } else {
+      SEGK_DISPATCH_DTYPE(dout_dtype, T,
+                          (upsample_bwd_pm_kernel<T, 4><<<(int)blocks, 256, 0, st>>>((const T*)dout, dout_ld, C, Ho, Wo, (T*)din,
+                                                                                    din_ld, din_cpad, Hi, Wi, sy, sx, total)));
+    }
   } else if (dout_layout == SEGK_NCHW) {
     SEGK_REQUIRE(dout_dtype == SEGK_F32, "upsample_bwd: the NCHW gradient is fp32");
     const long long rows = (long long)N * C * Ho;

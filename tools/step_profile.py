@@ -5,7 +5,9 @@ The process-wide --stats table also contains warm-up and MIOpen's one-time algor
 script cuts the trace between the last two launches of a once-per-step kernel (ce_fwd_kernel) and
 prints per-kernel totals for that interval: backward of step k-1 + optimizer + forward of step k.
 
-usage: tools/step_profile.py <kernel_trace.csv> [--top N]
+usage: tools/step_profile.py <kernel_trace.csv> [--top N] [--hist]
+--hist: for the convolution kernels, calls and time per duration class (which launches carry the time: the many
+short ones of the 33 x 33 stages or the few long ones of the head).
 """
 import collections
 import csv
@@ -43,6 +45,23 @@ def main():
     print("\nsegk kernels only:")
     for k, v in sorted(((k, v) for k, v in agg.items() if "segk::" in k), key=lambda kv: -kv[1][0]):
         print("%10.3f %6d %10.1f  %s" % (v[0] / 1e6, v[1], v[0] / v[1] / 1e3, k[:130]))
+    if "--hist" in sys.argv:
+        edges = [0, 10, 15, 20, 30, 45, 70, 110, 200, 400, 10 ** 9]
+        print("\nconvolution kernels by duration class (us): calls / total ms")
+        per = collections.defaultdict(lambda: [[0, 0] for _ in edges[:-1]])
+        for r in seg:
+            k = r["Kernel_Name"]
+            if "segk::conv_" not in k and "wgrad_finish" not in k:
+                continue
+            d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            for i in range(len(edges) - 1):
+                if edges[i] <= d < edges[i + 1]:
+                    per[k][i][0] += 1
+                    per[k][i][1] += d
+        for k, bins in sorted(per.items(), key=lambda kv: -sum(b[1] for b in kv[1])):
+            print(k[:110])
+            print("   " + "  ".join("%s-%s: %d / %.2f" % (edges[i], edges[i + 1] if edges[i + 1] < 10 ** 9 else "", b[0], b[1] / 1e3)
+                                    for i, b in enumerate(bins) if b[0]))
 
 
 if __name__ == "__main__":
