@@ -325,6 +325,13 @@ int segk_bn_bwd_apply(const void* dz, int dz_dtype, int dz_ld, const void* x, in
                       const uint8_t* mask, float mask_scale, const double* gsums, int eval, const void* act,
                       int act_ld, int act_bits, void* dres, int dres_ld, segk_stream_t stream);
 
+/* The keep-mask of nn.Dropout in training mode (modeling/aspp.py:128, modeling/decoder.py:146,151): mask[i] = 1 with
+ * probability 1 - p, else 0, one byte per element, the form segk_bn_apply's `mask` takes.  seed: two 64-bit words in
+ * DEVICE memory (key, stream offset) - the caller draws them from its own generator, inside a recorded graph as well,
+ * so that every replay gets a fresh mask; the same words give the same mask.  Philox4x32-10, 32 random bits per
+ * element.  0 <= p < 1; mask 16-byte aligned. */
+int segk_dropout_mask(uint8_t* mask, long long n, float p, const long long* seed, segk_stream_t stream);
+
 /* ---- pooling / resampling ------------------------------------------------------------------- */
 /* nn.AdaptiveAvgPool2d((1,1)) on a pixel-major tensor (modeling/aspp.py:121): out[n][c] fp32 =
  * scale * sum_pixels x[n][p][c]  (scale = 1/HW forward; 1 to sum a gradient). */

@@ -231,24 +231,33 @@ __global__ __launch_bounds__(256) void wgrad_finish_taps_kernel(const float* __r
   slabs += (size_t)gi * splits * slab;
   const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  for (int tap = 0; tap < TAPS; ++tap) {
+  // all 36 loads of a part are issued before its additions: with one or two parts (the head's 3 x 3 gradients over
+  // 2048 input channels) a walk tap by tap would leave one load in flight per thread
+  float acc[TAPS][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ci = ci0 + ty + i * 8, co = co0 + tx;
-      float acc = 0.f;
-      if (ci < Cin && co < Cout) {
-        const float* p = slabs + ((size_t)tap * Cin + ci) * Cout + co;
-        for (int s = 0; s < splits; s += 16) {
-          float v[16];
+  for (int tap = 0; tap < TAPS; ++tap)
 #pragma unroll
-          for (int u = 0; u < 16; ++u) v[u] = s + u < splits ? p[(size_t)(s + u) * slab] : 0.f;
+    for (int i = 0; i < 4; ++i) acc[tap][i] = 0.f;
+  const int co = co0 + tx;
+  for (int sp = 0; sp < splits; ++sp) {
+    const float* p = slabs + (size_t)sp * slab + co;
+    float v[TAPS][4];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) acc += v[u];
-        }
+    for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ci = ci0 + ty + i * 8;
+        v[tap][i] = (ci < Cin && co < Cout) ? p[((size_t)tap * Cin + ci) * Cout] : 0.f;
       }
-      tile[tap][ty + i * 8][tx] = acc;
-    }
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[tap][i] += v[tap][i];
   }
+#pragma unroll
+  for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tile[tap][ty + i * 8][tx] = acc[tap][i];
   __syncthreads();
   // row co: elements (ci0 .. ci0 + 31) x 9 taps are consecutive in dw
   for (int idx = threadIdx.x; idx < 32 * 32 * TAPS; idx += 256) {
@@ -280,13 +289,20 @@ __global__ __launch_bounds__(256) void wgrad_finish_tree_kernel(const float* __r
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
   if (co < Cout) {
-    for (int sp = ty; sp < splits; sp += 8) {
-      const float* p = slabs + sp * slab + ((size_t)tap * Cin + ci0) * Cout + co;
-      float v[8];
+    // four parts of this thread row per trip: 32 loads in flight, added in part order
+    for (int sp = ty; sp < splits; sp += 32) {
+      float v[4][8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = ci0 + i < Cin ? p[(size_t)i * Cout] : 0.f;
+      for (int q = 0; q < 4; ++q) {
+        const bool in = sp + 8 * q < splits;
+        const float* p = slabs + (size_t)(in ? sp + 8 * q : sp) * slab + ((size_t)tap * Cin + ci0) * Cout + co;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] += v[i];
+        for (int i = 0; i < 8; ++i) v[q][i] = in && ci0 + i < Cin ? p[(size_t)i * Cout] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += v[q][i];
     }
   }
 #pragma unroll
@@ -298,6 +314,50 @@ __global__ __launch_bounds__(256) void wgrad_finish_tree_kernel(const float* __r
 #pragma unroll
     for (int r = 0; r < 8; ++r) t += part[r][ty][tx];
     Elem<TD>::store(dw + co * s_co + ci * s_ci + tap * s_tap, t);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dropout keep-masks: one byte per element, 1 with probability 1 - p.  Philox4x32-10 keyed by a 64-bit seed, counter =
+// (index of the 16-element group, 64-bit stream offset): every element has 32 random bits of its own, whatever the
+// launch shape.  One launch writes the mask; drawing fp32 uniforms, comparing and narrowing took three launches and
+// eight times the bytes.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (unsigned)p1;
+    c[3] = (unsigned)p0;
+    c[0] = n0;
+    c[2] = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ mask, long long n, unsigned threshold,
+                                                           const long long* __restrict__ seed) {
+  const unsigned long long key = (unsigned long long)seed[0], stream_off = (unsigned long long)seed[1];
+  const long long groups = (n + 15) / 16;
+  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < groups; g += (long long)gridDim.x * 256) {
+    unsigned w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned c[4] = {(unsigned)((unsigned long long)g * 4 + q), (unsigned)(((unsigned long long)g * 4 + q) >> 32),
+                       (unsigned)stream_off, (unsigned)(stream_off >> 32)};
+      philox4x32_10(c, (unsigned)key, (unsigned)(key >> 32));
+      w[q] = (c[0] >= threshold ? 1u : 0u) | (c[1] >= threshold ? 0x100u : 0u) | (c[2] >= threshold ? 0x10000u : 0u) |
+             (c[3] >= threshold ? 0x1000000u : 0u);
+    }
+    const long long e0 = g * 16;
+    if (e0 + 16 <= n) {
+      u32x4 t = {w[0], w[1], w[2], w[3]};
+      *reinterpret_cast<u32x4*>(mask + e0) = t;
+    } else {
+      for (long long e = e0; e < n; ++e) mask[e] = (uint8_t)((w[(e - e0) >> 2] >> (8 * ((e - e0) & 3))) & 0xffu);
+    }
   }
 }
 
@@ -463,4 +523,19 @@ extern "C" int segk_wgrad_finish(const float* slabs, int splits, int R, int Cin,
   const long long taps = (long long)R * R;
   return segk_wgrad_finish_strided(slabs, splits, R, Cin, Cout, dw, SEGK_F32, (long long)Cin_true * taps, taps, 1,
                                    Cout_true, Cin_true, stream);
+}
+
+extern "C" int segk_dropout_mask(uint8_t* mask, long long n, float p, const long long* seed, segk_stream_t stream) {
+  SEGK_REQUIRE(mask && seed && n > 0, "dropout_mask: null pointer or n=%lld", n);
+  SEGK_REQUIRE(p >= 0.f && p < 1.f, "dropout_mask: p=%g outside [0, 1)", (double)p);
+  SEGK_REQUIRE(((uintptr_t)mask % 16) == 0 && ((uintptr_t)seed % 8) == 0, "dropout_mask: unaligned buffers");
+  // an element is dropped when its 32 random bits fall below p * 2^32
+  const double scaled = (double)p * 4294967296.0;
+  const unsigned threshold = scaled >= 4294967295.0 ? 4294967295u : (unsigned)(scaled + 0.5);
+  const long long groups = (n + 15) / 16;
+  long long blocks = (groups + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  dropout_mask_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(mask, n, threshold, seed);
+  SEGK_CHECK_LAUNCH("dropout_mask");
+  return SEGK_OK;
 }

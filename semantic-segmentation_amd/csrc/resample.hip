@@ -284,6 +284,9 @@ __global__ __launch_bounds__(256) void upsample_bwd_pm_kernel(const TG* __restri
       int ylo, yhi, xlo, xhi;
       reader_range(iy, sy, Ho, ylo, yhi);
       reader_range(ix, sx, Wo, xlo, xhi);
+      // the range is conservative: drop the columns at its ends that do not read this pixel (loads, not just weights)
+      while (xlo < xhi && tap_weight(xlo, ix, sx, Wi) == 0.f) ++xlo;
+      while (xhi > xlo && tap_weight(xhi, ix, sx, Wi) == 0.f) --xhi;
       const TG* b = dout + (size_t)n * Ho * Wo * dout_ld + c0;
       for (int oy = ylo; oy <= yhi; ++oy) {
         const float wy = tap_weight(oy, iy, sy, Hi);

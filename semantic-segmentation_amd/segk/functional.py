@@ -160,6 +160,8 @@ def _dropout_mask(shape, p, device, geom=None):
             raise ValueError("injected dropout mask has shape %s, expected %s" % (tuple(given.shape), (N, shape[1], H, W)))
         keep = (given.to(device) != 0).permute(0, 2, 3, 1).reshape(shape)
         return keep.to(torch.uint8).contiguous(), 1.0 / (1.0 - p)
+    if torch.device(device).type == "cuda":
+        return ops.dropout_mask(shape, p, device), 1.0 / (1.0 - p)
     keep = torch.rand(shape, device=device) >= p
     return keep.to(torch.uint8), 1.0 / (1.0 - p)
 

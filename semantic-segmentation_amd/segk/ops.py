@@ -989,6 +989,23 @@ def bn_bwd_apply(dz, x, dx, coef, gsums, layout, relu, mask=None, mask_scale=1.0
     return dx
 
 
+def dropout_mask(shape, p, device):
+    """uint8 keep-mask of `shape` (1 with probability 1 - p) in one launch.  The Philox key and stream offset are two
+    int64 drawn on the device from torch's generator: torch.manual_seed fixes the masks, and inside a recorded
+    graph every replay draws new ones."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    mask = torch.empty(tuple(shape), dtype=torch.uint8, device=device)
+    if n == 0:
+        return mask
+    seed = torch.randint(-(1 << 62), 1 << 62, (2,), dtype=torch.int64, device=device)
+    t0 = _hbm_start()
+    call("segk_dropout_mask", _ptr(mask), n, ctypes.c_float(p), _ptr(seed), _stream())
+    _hbm_stop("dropout_mask", n, t0)
+    return mask
+
+
 # ------------------------------------------------------- pooling / resample ----
 def pool_sum(x, N, HW, scale):
     """x: pixel-major view [N*HW, C] -> [N, C] float32 = scale * sum over the pixels of each image."""

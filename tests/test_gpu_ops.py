@@ -646,6 +646,34 @@ def test_bn_residual_relu_fused(ops, dtype, tol):
     assert torch.equal(sums2, sums) and torch.equal(dx2, dx) and torch.equal(dres2, dres)
 
 
+@pytest.mark.parametrize("p", [0.5, 0.1])
+def test_dropout_mask_statistics_and_seeding(ops, p):
+    """The one-launch keep-mask of nn.Dropout (modeling/decoder.py:146,151): bytes 0 / 1, kept with probability 1 - p
+    (five standard deviations), neighbours and far-apart elements independent, fixed by torch.manual_seed, new on
+    every call.  1 000 003 elements: the last group of sixteen is partial."""
+    n = 1000003
+    torch.manual_seed(1234)
+    a = ops.dropout_mask((n,), p, DEV)
+    b = ops.dropout_mask((n,), p, DEV)
+    torch.manual_seed(1234)
+    a2 = ops.dropout_mask((n,), p, DEV)
+    assert a.dtype == torch.uint8 and int(a.max()) == 1 and int(a.min()) == 0
+    assert torch.equal(a, a2) and not torch.equal(a, b)
+    q = 1.0 - p
+    sd = (q * p / n) ** 0.5
+    for m in (a, b):
+        assert abs(float(m.float().mean()) - q) < 5 * sd
+    af, bf = a.float(), b.float()
+    for lag in (1, 4, 16, 4096):
+        joint = float((af[:-lag] * af[lag:]).mean())
+        assert abs(joint - q * q) < 5 * (q * q * (1 - q * q) / (n - lag)) ** 0.5, (lag, joint)
+    assert abs(float((af * bf).mean()) - q * q) < 5 * (q * q * (1 - q * q) / n) ** 0.5
+    # a two-dimensional shape is the same stream laid out row after row
+    torch.manual_seed(1234)
+    c = ops.dropout_mask((1000, 1000), p, DEV)
+    assert torch.equal(c.reshape(-1), a[:1000000])
+
+
 def test_debug_labels_raises_on_out_of_range_labels():
     """config.set_debug_labels: a label that is neither the ignore index nor a class raises, like the reference's
     nn.CrossEntropyLoss does (/root/reference/utils/loss.py:25-30); without the switch the kernels ignore it."""
