@@ -364,15 +364,16 @@ def main():
             opt = torch.optim.SGD(groups, momentum=0.9, weight_decay=5e-4, nesterov=False)
         criterion = SegmentationLosses(weight=None, cuda=True).build_loss("ce")
         scheduler = LR_Scheduler("poly", 0.007, 50, 1000, quiet=True)
-        buckets = parallel.GradientBuckets([p for g in opt.param_groups for p in g["params"]],
-                                           overlap=world > 1 and args.optimizer == "hip")
         image, target = synthetic_batch(args.batch, args.size, args.classes, dev, 1 + rank)
 
-        # (ranks > 1: only when every exchange of the step is a launch of this library - statistics, loss sums AND
-        # gradient buckets through the mailboxes, SEGK_GRAD_EXCHANGE=mailbox, a rehearsal path; with the buckets on
-        # RCCL the step is issued eagerly)
-        use_graph = args.optimizer == "hip" and (args.graph == "on" or (args.graph == "auto" and (
-            world == 1 or parallel.step_is_capturable())))
+        # ranks > 1: recorded when the batch-norm statistics and loss sums travel through the mailboxes (launches of
+        # this library); the gradient buckets then either go through them too (SEGK_GRAD_EXCHANGE=mailbox, a rehearsal
+        # path: one graph) or through RCCL between two graphs (segk.graph).  Without mailboxes the step is issued
+        # eagerly and the buckets' all-reduces start from parameter hooks, under the backward pass.
+        use_graph = args.optimizer == "hip" and args.graph != "off" and (
+            world == 1 or parallel.step_is_capturable() or parallel.mailbox_active())
+        buckets = parallel.GradientBuckets([p for g in opt.param_groups for p in g["params"]],
+                                           overlap=world > 1 and args.optimizer == "hip" and not use_graph)
         config.set_overlap_wgrad(args.overlap_wgrad == "on" or (args.overlap_wgrad == "auto" and use_graph))
 
         def step(i):
@@ -434,7 +435,7 @@ def main():
         if world > 1:
             parallel.check_exchange()   # raises if an in-kernel wait of the mailbox path timed out
         res = {"final_loss": float(loss.detach()), "feeder_amp": feeder_amp, "conv": None, "hbm": None,
-               "graph": use_graph}
+               "graph": use_graph, "graph_split": bool(use_graph and stepper.split)}
         if detailed and use_graph:
             # the launches of a replayed graph cannot be bracketed one by one: the same number of steps again,
             # issued eagerly with HIP events around every convolution call, right behind the timed region
@@ -546,8 +547,11 @@ def main():
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "collectives": ("RCCL (torch.distributed nccl backend)" if backend == "nccl" else backend) if world > 1 else None,
                        "small_exchanges": parallel.exchange_description(),
-                       "launch": ("one HIP graph per training iteration (segk.graph.GraphedTrainStep): recorded after the "
-                                  "warm-up, replayed in the timed region; learning-rate schedule on the host"
+                       "launch": (("two HIP graphs per training iteration (segk.graph.GraphedTrainStep: forward + backward "
+                                   "+ bucket packing, then the optimizer) with the buckets' all-reduce issued between their "
+                                   "replays" if main_res.get("graph_split") else
+                                   "one HIP graph per training iteration (segk.graph.GraphedTrainStep)") +
+                                  ": recorded after the warm-up, replayed in the timed region; learning-rate schedule on the host"
                                   if main_res["graph"] else "eager: one host call per kernel launch"),
                        "feeder_3x3_convs": config.feeder_conv(),
                        "kernel_timing": ("HIP events around each convolution call in %d eagerly issued steps right after "

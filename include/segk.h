@@ -467,6 +467,9 @@ int segk_allreduce_i64(int64_t* buf, long long count, segk_stream_t stream);
  *                         (SEGK_MAILBOX_HANDLE_BYTES) to handle_out;
  *   segk_mailbox_connect  takes the `world` handles in rank order (exchanged by the host by any means), maps the
  *                         peers' mailboxes; timeout_ms bounds every in-kernel wait (<= 0: 60 000);
+ *   segk_mailbox_set_timeout  the same bound for the launches issued from now on (a short one for a connection test
+ *                         between ranks that have just met at a host barrier, a long one for training, where the
+ *                         first step's algorithm search can hold a rank back for seconds);
  *   segk_mailbox_allreduce_f64 / _f32: buf[0..n) on the device, any n (vectors longer than SEGK_MAILBOX_MAX_DOUBLES
  *                         go through in chunks inside the one launch; sums are formed in fp64 and rounded once);
  *                         every rank must issue the same sequence of calls;
@@ -476,6 +479,7 @@ int segk_allreduce_i64(int64_t* buf, long long count, segk_stream_t stream);
 #define SEGK_MAILBOX_MAX_DOUBLES 4352
 int segk_mailbox_create(int world, void* handle_out);
 int segk_mailbox_connect(int rank, int world, const void* handles, int timeout_ms);
+int segk_mailbox_set_timeout(int timeout_ms);
 int segk_mailbox_allreduce_f64(double* buf, long long n, segk_stream_t stream);
 int segk_mailbox_allreduce_f32(float* buf, long long n, segk_stream_t stream);
 long long segk_mailbox_status(void);

@@ -289,6 +289,12 @@ extern "C" int segk_mailbox_connect(int rank, int world, const void* handles, in
   return SEGK_OK;
 }
 
+extern "C" int segk_mailbox_set_timeout(int timeout_ms) {
+  SEGK_REQUIRE(g_mbx.connected, "mailbox_set_timeout: segk_mailbox_connect has not been called");
+  g_mbx.peers.timeout_ticks = (unsigned long long)(timeout_ms > 0 ? timeout_ms : 60000) * 100000ull;
+  return SEGK_OK;
+}
+
 extern "C" int segk_mailbox_allreduce_f64(double* buf, long long n, segk_stream_t stream) {
   int rc = mailbox_launch_check(buf, n);
   if (rc != SEGK_OK) return rc;

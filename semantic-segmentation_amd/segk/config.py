@@ -81,8 +81,8 @@ def set_overlap_wgrad(flag):
     gradient; a matrix-bound launch beside memory-bound ones fills the chip better than either alone).  The
     gradients are then written to ``weight.grad`` by an end-of-backward callback after the streams have joined,
     not returned through autograd: use it with ``.backward()`` loops only (``torch.autograd.grad`` would see None
-    for those weights, and hooks on the weights do not fire).  Ignored while gradients are exchanged between ranks:
-    the bucketed all-reduce hangs on parameter hooks.  Default False."""
+    for those weights, and hooks on the weights do not fire).  Ignored while a segk.parallel.GradientBuckets with
+    overlap=True exists: its all-reduces are started from parameter hooks.  Default False."""
     _state["overlap_wgrad"] = bool(flag)
 
 

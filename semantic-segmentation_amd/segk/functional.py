@@ -279,7 +279,7 @@ def weight_grad(weight, x, dy, N, H, W, R, dil, Cout, Cin, like=None):
     """dW of one convolution.  Returns the gradient, or None when it was started (or queued for a launch together with
     others of its shape) on the second stream and will be stored in weight.grad at the end of the running backward
     pass (config.overlap_wgrad, config.group_wgrad)."""
-    deferred = (config.overlap_wgrad() and not parallel.is_distributed() and isinstance(weight, torch.Tensor)
+    deferred = (config.overlap_wgrad() and not parallel.grad_hooks_active() and isinstance(weight, torch.Tensor)
                 and weight.is_leaf and weight.requires_grad and x.is_cuda)
     if not deferred:
         return ops.conv_wgrad(x, dy, N, H, W, R, dil, Cout, Cin, like=like)

@@ -14,9 +14,14 @@ optimizer launch of ``segk.optim.SGD`` reads its hyper-parameters from device me
 PyTorch's graph-aware generator state.  Batch-norm running statistics, momentum buffers and weights are updated in
 place by the replayed kernels, so ``state_dict()`` / checkpoints see them as after eager iterations.
 
-Restrictions: the shapes of the batch are fixed at construction; a step whose ranks exchange through
-torch.distributed collectives is refused (run those steps eagerly) - exchanges through the mailboxes of
-segk.parallel are launches of this library and are recorded like any other; the model must not
+Data-parallel jobs: exchanges through the mailboxes of segk.parallel (batch-norm statistics, loss sums) are launches
+of this library and are recorded like any other.  Gradient buckets that travel through torch.distributed (RCCL) stay
+outside: the iteration is then recorded as TWO graphs - everything up to the packed buckets, and the optimizer
+launch - with ``buckets.exchange_flat()`` issued between their replays (three host calls per iteration instead of
+some 1 400; the all-reduce does not overlap the backward pass).
+
+Restrictions: the shapes of the batch are fixed at construction; a step whose batch norms or loss exchange through
+torch.distributed collectives is refused (run those steps eagerly, or connect the mailboxes); the model must not
 synchronise with the host inside the iteration (``.item()``, printing a loss) - read the returned loss tensor after
 the call instead.
 """
@@ -32,10 +37,12 @@ class GraphedTrainStep:
         buckets: the segk.parallel.GradientBuckets of a data-parallel job; the iteration then ends with
         ``optimizer.step(flat_grads=buckets.reduce_flat())``."""
         from . import parallel
-        if not parallel.step_is_capturable():
-            raise RuntimeError("GraphedTrainStep: a step with torch.distributed collectives (world size %d) is not "
-                               "recorded; run it eagerly, or send every exchange through the mailboxes "
-                               "(segk.parallel.connect_mailboxes(gradients=True))" % dist.get_world_size())
+        # two graphs with the bucket all-reduce between them when only the buckets are on torch.distributed
+        self.split = not parallel.step_is_capturable()
+        if self.split and not (parallel.mailbox_active() and buckets is not None):
+            raise RuntimeError("GraphedTrainStep: a step whose batch norms and loss exchange through torch.distributed "
+                               "collectives (world size %d) is not recorded; run it eagerly, or connect the mailboxes "
+                               "(segk.parallel.connect_mailboxes) and pass the GradientBuckets" % dist.get_world_size())
         if not image.is_cuda:
             raise RuntimeError("GraphedTrainStep: the batch must live on the GPU")
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
@@ -58,21 +65,36 @@ class GraphedTrainStep:
             torch.cuda.synchronize(image.device)
         optimizer.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self.stream):
-            self.loss = self._iteration()
+        self.graph_step = None
+        if not self.split:
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self.loss = self._iteration()
+        else:
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self.loss = self._forward_backward()
+                self.buckets.pack_flat()
+            self.graph_step = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_step, stream=self.stream, pool=self.graph.pool()):
+                self.optimizer.step(flat_grads=self.buckets)
 
-    def _iteration(self):
+    def _forward_backward(self):
         self.optimizer.zero_grad(set_to_none=True)
         if self.loss_fn is not None:
             loss = self.loss_fn(self.image, self.target)
         else:
             loss = self.criterion(self.model(self.image), self.target)
         loss.backward()
-        if self.buckets is not None:
+        return loss.detach()
+
+    def _iteration(self):
+        loss = self._forward_backward()
+        if self.split:
+            self.optimizer.step(flat_grads=self.buckets.pack_flat().exchange_flat())
+        elif self.buckets is not None:
             self.optimizer.step(flat_grads=self.buckets.reduce_flat())
         else:
             self.optimizer.step()
-        return loss.detach()
+        return loss
 
     def __call__(self, image, target):
         """One iteration on the given batch (same shapes and dtypes as at construction).  Returns the loss tensor of
@@ -90,6 +112,9 @@ class GraphedTrainStep:
             raise RuntimeError("GraphedTrainStep: the learning rate changed, but this optimizer's recorded launch keeps "
                                "the value it was recorded with; use segk.optim.SGD")
         self.graph.replay()
+        if self.graph_step is not None:
+            self.buckets.exchange_flat()
+            self.graph_step.replay()
         if self._after_replay is not None:
             self._after_replay()
         return self.loss

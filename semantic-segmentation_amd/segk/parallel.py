@@ -115,7 +115,10 @@ def connect_mailboxes(timeout_ms=0, self_test=True, gradients=None):
         return False
     _MAILBOX["on"] = True
     if self_test:
+        # the ranks have just met in all_gather_object: a peer that does not answer within seconds never will
+        _lib.call("segk_mailbox_set_timeout", 5000)
         good = _mailbox_self_test(me, world)
+        _lib.call("segk_mailbox_set_timeout", int(timeout_ms))
         flags = [None] * world
         dist.all_gather_object(flags, good)
         if not all(flags):
@@ -211,18 +214,32 @@ def _host_staged(t):
     return t.is_cuda and dist.get_backend() == "gloo"
 
 
+def _host_all_reduce(t):
+    h = t.cpu()
+    dist.all_reduce(h, op=dist.ReduceOp.SUM)
+    t.copy_(h)
+    return t
+
+
 def all_reduce_sum_(t):
     """In-place SUM all-reduce on the current stream; identity on one rank."""
     if is_distributed():
         if _MAILBOX["on"] and t.is_cuda:
             _mailbox_all_reduce(t)
         elif _host_staged(t):
-            h = t.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.SUM)
-            t.copy_(h)
+            _host_all_reduce(t)
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
+
+
+_HOOKED_BUCKETS = [0]   # GradientBuckets(overlap=True) created in this process
+
+
+def grad_hooks_active():
+    """Whether some GradientBuckets start their all-reduces from parameter hooks: weight gradients must then reach
+    ``weight.grad`` through autograd's accumulation nodes (segk.functional.weight_grad does not defer them)."""
+    return _HOOKED_BUCKETS[0] > 0
 
 
 class GradientBuckets:
@@ -266,7 +283,9 @@ class GradientBuckets:
         self._next = 0         # first bucket not started yet (hook path)
         self._dirty = set()    # buckets that received gradients again after their all-reduce was started
         self._bucket_of = {id(p): k for k, b in enumerate(self.buckets) for p in b}
+        self._hooked = bool(overlap)
         if overlap:
+            _HOOKED_BUCKETS[0] += 1
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
@@ -309,8 +328,8 @@ class GradientBuckets:
                 self._gather.append((StagedTable(t, flat.device), tidx, offs * esz))
         return flats
 
-    def _start(self, k):
-        """Pack bucket k from the gradients as they are now and start its all-reduce."""
+    def _start(self, k, exchange=True):
+        """Pack bucket k from the gradients as they are now and (exchange) start its all-reduce."""
         import ctypes
 
         import numpy as np
@@ -336,13 +355,19 @@ class GradientBuckets:
         if n:
             _lib.call("segk_gather_f32", ctypes.c_void_p(staged.ptr()), n,
                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if exchange:
+            self._exchange(k)
+
+    def _exchange(self, k):
+        """Start the all-reduce of the packed bucket k."""
+        flat = self._buffers()[k]
         if not is_distributed():
             self._works[k] = None
         elif _MAILBOX["on"] and _MAILBOX["grads"]:
             _mailbox_all_reduce(flat)
             self._works[k] = None
         elif _host_staged(flat):
-            all_reduce_sum_(flat)
+            _host_all_reduce(flat)   # (the buckets stay on torch.distributed even when the mailboxes carry the statistics)
             self._works[k] = None
         else:
             self._works[k] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
@@ -365,6 +390,25 @@ class GradientBuckets:
         self._ready = set()
         self._next = 0
         self._dirty = set()
+        return self
+
+    def pack_flat(self):
+        """First half of reduce_flat(): every gradient into its bucket, nothing exchanged (launches of this library
+        only - the half a recorded graph can hold when the buckets travel through torch.distributed)."""
+        if self._hooked:
+            raise RuntimeError("GradientBuckets(overlap=True) packs and reduces from hooks; use overlap=False")
+        for k in range(len(self.buckets)):
+            self._start(k, exchange=False)
+        return self
+
+    def exchange_flat(self):
+        """Second half: all-reduce the packed buckets and wait."""
+        for k in range(len(self.buckets)):
+            self._exchange(k)
+        for w in self._works.values():
+            if w is not None:
+                w.wait()
+        self._works = {}
         return self
 
     def _buffers(self):
@@ -393,8 +437,11 @@ class GradientBuckets:
                 else:
                     flat[off:off + n].copy_(p.grad.reshape(-1))
                 off += n
-            if (_MAILBOX["on"] and _MAILBOX["grads"]) or _host_staged(flat):
-                all_reduce_sum_(flat) if not _MAILBOX["on"] else _mailbox_all_reduce(flat)
+            if _MAILBOX["on"] and _MAILBOX["grads"]:
+                _mailbox_all_reduce(flat)
+                works.append(None)
+            elif _host_staged(flat):
+                _host_all_reduce(flat)
                 works.append(None)
             else:
                 works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))

@@ -205,6 +205,7 @@ def train_steps(device, images, steps, graphed):
     losses = []
     if graphed:
         stepper = GraphedTrainStep(net, crit, opt, batches[0][0], batches[0][1], warmup=2, buckets=buckets)
+        assert stepper.split == (not parallel.step_is_capturable())
         for img, tgt in batches[2:]:
             losses.append(float(stepper(img, tgt)))
     else:
@@ -220,14 +221,16 @@ def train_steps(device, images, steps, graphed):
     return losses, {n: p.detach().float().cpu().numpy() for n, p in net.named_parameters()}
 
 
-def run_mailbox(rank, world, outdir):
+def run_mailbox(rank, world, outdir, gradients=True):
     """Every exchange through the peer-mapped mailboxes: the case of run_gpu (one step, statistics + loss sums +
     gradient buckets), then five SGD iterations issued eagerly and the same five with the last three replayed from
-    a HIP graph, with the cross-rank comparison of the statistics switched on for the eager ones."""
+    a HIP graph, with the cross-rank comparison of the statistics switched on for the eager ones.
+    gradients=False: the buckets stay on torch.distributed (gloo here, RCCL in production); the replayed iteration
+    is then two graphs with the buckets' all-reduce between them, and its weight gradients run on the second stream."""
     from segk import config, parallel
     if world > 1:
-        assert parallel.connect_mailboxes(timeout_ms=20000, gradients=True), parallel.exchange_description()
-        assert parallel.step_is_capturable()
+        assert parallel.connect_mailboxes(timeout_ms=20000, gradients=gradients), parallel.exchange_description()
+        assert parallel.step_is_capturable() == gradients and parallel.mailbox_active()
     run_gpu(rank, world, outdir)
     res = dict(np.load(os.path.join(outdir, "rank%d.npz" % rank)))
     per = GPU_N // world
@@ -238,7 +241,8 @@ def run_mailbox(rank, world, outdir):
     config.set_debug_sync_stats(True)
     eager_losses, eager_w = train_steps("cuda:0", shard_, 5, graphed=False)
     config.set_debug_sync_stats(False)
-    graph_losses, graph_w = train_steps("cuda:0", shard_, 5, graphed=True)
+    with config.overlap_wgrad_as(not gradients):
+        graph_losses, graph_w = train_steps("cuda:0", shard_, 5, graphed=True)
     torch.use_deterministic_algorithms(False)
     res["eager_losses"], res["graph_losses"] = np.array(eager_losses), np.array(graph_losses)
     for n, v in eager_w.items():
@@ -253,7 +257,7 @@ def main():
     mode, rank, world, port, outdir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import faulthandler
-    faulthandler.dump_traceback_later(180 if mode == "mbx" else 60, exit=True)  # a stuck collective names its call site instead of hanging the test
+    faulthandler.dump_traceback_later(180 if mode in ("mbx", "split") else 60, exit=True)  # a stuck collective names its call site instead of hanging the test
     if mode == "nccl":   # one rank per device over RCCL, the production transport
         torch.cuda.set_device(rank)
     if world > 1:
@@ -264,9 +268,9 @@ def main():
         run_cpu(rank, world, outdir)
     elif mode == "nccl":
         run_gpu(rank, world, outdir, device="cuda:%d" % rank)
-    elif mode == "mbx":
+    elif mode in ("mbx", "split"):
         torch.cuda.set_device(0)
-        run_mailbox(rank, world, outdir)
+        run_mailbox(rank, world, outdir, gradients=mode == "mbx")
     else:
         torch.cuda.set_device(0)
         run_gpu(rank, world, outdir)

@@ -142,6 +142,30 @@ def test_two_ranks_through_mailboxes_eager_and_graph_replay():
 
 
 @pytest.mark.gpu
+def test_two_ranks_two_graphs_with_the_bucket_exchange_between():
+    """Statistics and loss sums through the mailboxes, gradient buckets through torch.distributed (what RCCL carries
+    in production): the replayed iteration is two graphs - forward, backward and bucket packing; the optimizer - with
+    the all-reduce between them, weight gradients on the second stream.  Replayed losses equal the eagerly issued
+    ones, both ranks end with the same weights."""
+    assert torch.cuda.is_available()
+    with tempfile.TemporaryDirectory() as d:
+        ranks = launch("split", 2, d)
+        single = launch("gpu", 1, d)[0]
+    _check_ranks_against_single(ranks, single, 1e-3)
+    for r in ranks:
+        assert r["exchanges"][0] > 50, r["exchanges"]
+        assert len(r["graph_losses"]) == 3
+        assert np.allclose(r["graph_losses"], r["eager_losses"], rtol=2e-4), (r["graph_losses"], r["eager_losses"])
+    assert np.array_equal(ranks[0]["graph_losses"], ranks[1]["graph_losses"])
+    for k in ranks[0]:
+        if k.startswith(("wg/", "we/")):
+            assert np.array_equal(ranks[0][k], ranks[1][k]), k
+    from helpers import rel_l2
+    worst = max(rel_l2(ranks[0]["wg/" + k[3:]], v) for k, v in ranks[0].items() if k.startswith("we/"))
+    assert worst < 5e-3, worst
+
+
+@pytest.mark.gpu
 def test_ranks_on_separate_devices_rccl():
     """One rank per device over RCCL (torch.distributed backend "nccl"): 2 devices x half the batch equal one
     device x the whole batch (/root/reference/train.py:105-110 with --gpu-ids 0,1)."""
