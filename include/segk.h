@@ -130,6 +130,12 @@ typedef struct {
    * a multiple of 128, no biases, batch <= 1; SEGK_UNSUPPORTED_SHAPE otherwise. */
   const void* addend;
   int addend_ld;
+  /* NULL, or [M][addend_bits_ld] bytes beside the addend: bit c % 8 of byte c / 8 set = addend[m][c] is added, clear =
+   * zero is added.  It is the ReLU pattern segk_bn_apply stored for the block's last unit: the shortcut's gradient is
+   * the block's incoming gradient where the ReLU was active, so the consumer masks that gradient itself and the
+   * batch norm's backward need not write a masked copy (segk_bn_bwd_apply with dres = NULL). */
+  const void* addend_bits;
+  int addend_bits_ld;
 } segk_conv_args;
 
 /* nn.Conv2d forward (modeling/aspp.py:18, modeling/decoder.py:172,178) and, with transposed packed
@@ -316,7 +322,8 @@ int segk_bn_bwd_stats(const void* dz, int dz_dtype, int dz_ld, const void* x, in
                       const float* shift, int relu, const uint8_t* mask, float mask_scale, const void* act,
                       int act_ld, int act_bits, double* partials, segk_stream_t stream);
 /* Backward, pass 2 (act / act_bits as in pass 1; dres, NULL or [M][dres_ld] of dz's dtype, receives g = the gradient
- * of the residual input): dx = scale * (g - sum_g/count - xhat * sum_gxhat/count) with the GLOBAL sums
+ * of the residual input; NULL with act given: the caller derives it from dz and the bit pattern itself, see
+ * segk_conv_args.addend_bits): dx = scale * (g - sum_g/count - xhat * sum_gxhat/count) with the GLOBAL sums
  * gsums = [sum g (C), sum g*xhat (C), count] (autograd of batchnorm.py:66-73 through the reduction);
  * eval != 0: dx = scale * g.  */
 int segk_bn_bwd_apply(const void* dz, int dz_dtype, int dz_ld, const void* x, int x_dtype, int x_ld, void* dx,

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_pm_kernel(
     if (RES == 2) bits = reinterpret_cast<const uint8_t*>(act)[m * act_ld + (c0 >> 3)];
     grad_through_act<VEC>(gz, xv, sc, sh, relu, mask ? mask + m * C + c0 : nullptr, mask_scale,
                           RES == 1 ? av : nullptr, bits);
-    if (RES) store_vec<TG, VEC>(dres + m * dres_ld + c0, gz);   // gradient of the residual input
+    if (RES && dres) store_vec<TG, VEC>(dres + m * dres_ld + c0, gz);   // gradient of the residual input (unless the consumer masks dz itself)
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
       o[j] = eval ? sc[j] * gz[j] : sc[j] * (gz[j] - k1[j] - (xv[j] - mu[j]) * is[j] * k2[j]);
@@ -897,7 +897,7 @@ extern "C" int segk_bn_bwd_apply(const void* dz, int dz_dtype, int dz_ld, const 
   if (layout == SEGK_PM) {
     SEGK_REQUIRE(x_ld >= C && dz_ld >= C && dx_ld >= C, "bn_bwd_apply: ld (%d,%d,%d) < C %d", dz_ld, x_ld, dx_ld, C);
     const long long M = (long long)N * HW;
-    SEGK_REQUIRE((act != nullptr) == (dres != nullptr), "bn_bwd_apply: a stored activation and a residual gradient come together");
+    SEGK_REQUIRE(act != nullptr || dres == nullptr, "bn_bwd_apply: a residual gradient needs the stored activation");
     SEGK_REQUIRE((!act || (act_bits ? act_ld * 8 >= C : act_ld >= C)) && (!dres || dres_ld >= C),
                  "bn_bwd_apply: ld (%d,%d) < C %d", act_ld, dres_ld, C);
     SEGK_REQUIRE(!act_bits || act, "bn_bwd_apply: act_bits without act");

@@ -65,6 +65,8 @@ struct ConvDev {
   const float* img_bias;
   const char* addend;    // nullptr, or [M][addend_ld] of the output dtype, added to the rounded result (ring tile only)
   long long addend_ld_b;
+  const uint8_t* addend_bits;   // nullptr, or [M][addend_bits_ld] bytes: bit c % 8 of byte c / 8 keeps addend[m][c], a clear bit adds zero
+  int addend_bits_ld;
   double* stat;
   long long m_begin;     // first pixel of this launch (a problem may be cut into a main and a tail launch)
   long long stat_row0;   // statistic partial row of this launch's first pixel tile
@@ -124,6 +126,11 @@ __device__ __forceinline__ unsigned int add_bf16x2(unsigned int a, unsigned int 
   const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
   const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u);
   return pack_bf16x2(lo, hi);
+}
+
+// the bf16 pair `v` with the element of a clear bit replaced by +0.0: bits b0 (low half) and b1 (high half)
+__device__ __forceinline__ unsigned int keep_bf16x2(unsigned int v, unsigned int b0, unsigned int b1) {
+  return v & ((b0 ? 0x0000ffffu : 0u) | (b1 ? 0xffff0000u : 0u));
 }
 
 // Tile geometry: a workgroup owns BCO output channels x BPX pixels with WCO x WPX wavefronts; each wavefront
@@ -2088,7 +2095,12 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
               u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
               if (m < p.M) {
                 if (p.addend) {
-                  const u32x4 ad = *reinterpret_cast<const u32x4*>(p.addend + (size_t)m * p.addend_ld_b + (size_t)cbase * 2 + i * 32);
+                  u32x4 ad = *reinterpret_cast<const u32x4*>(p.addend + (size_t)m * p.addend_ld_b + (size_t)cbase * 2 + i * 32);
+                  if (p.addend_bits) {   // this lane's eight channels are one byte of the pattern
+                    const unsigned b = p.addend_bits[(size_t)m * p.addend_bits_ld + ((cbase + i * 16) >> 3)];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ad[e] = keep_bf16x2(ad[e], (b >> (2 * e)) & 1u, (b >> (2 * e + 1)) & 1u);
+                  }
 #pragma unroll
                   for (int e = 0; e < 4; ++e) o[e] = add_bf16x2(o[e], ad[e]);
                 }
@@ -2106,12 +2118,18 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
         const size_t coff = (size_t)(co0 + wr * (MI * 16) + fg * 4) * sizeof(TO);
         char* orow = obase + (size_t)m * p.out_ld * sizeof(TO) + coff;
         const char* arow = p.addend ? p.addend + (size_t)m * p.addend_ld_b + coff : nullptr;
+        const uint8_t* brow = p.addend_bits ? p.addend_bits + (size_t)m * p.addend_bits_ld : nullptr;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
           float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
           if (arow) {
+            // the four channels of this lane: one nibble of the pattern
+            const int c4 = co0 + wr * (MI * 16) + i * 16 + fg * 4;
+            const unsigned nb = brow ? (brow[c4 >> 3] >> (c4 & 4)) & 15u : 15u;
             if constexpr (sizeof(TO) == 2) {
-              const u32x2 ad = *reinterpret_cast<const u32x2*>(arow + i * 32);
+              u32x2 ad = *reinterpret_cast<const u32x2*>(arow + i * 32);
+              ad[0] = keep_bf16x2(ad[0], nb & 1u, nb & 2u);
+              ad[1] = keep_bf16x2(ad[1], nb & 4u, nb & 8u);
               const unsigned r0 = add_bf16x2(pack_bf16x2(o[0], o[1]), ad[0]), r1 = add_bf16x2(pack_bf16x2(o[2], o[3]), ad[1]);
               const u32x2 t = {r0, r1};
               *reinterpret_cast<u32x2*>(orow + i * 32) = t;
@@ -2119,7 +2137,7 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
             } else {
               const f32x4 ad = *reinterpret_cast<const f32x4*>(arow + i * 64);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) o[r] += ad[r];
+              for (int r = 0; r < 4; ++r) o[r] += ((nb >> r) & 1u) ? ad[r] : 0.f;
             }
           }
           store_out4<TO>(orow + i * 16 * sizeof(TO), o);
@@ -2737,6 +2755,8 @@ static bool fill_dev(const segk_conv_args* a, ConvDev& d) {
   d.bias = a->bias; d.img_bias = a->img_bias; d.stat = a->stat_partials;
   d.addend = (const char*)a->addend;
   d.addend_ld_b = (long long)a->addend_ld * dtype_size(a->out_dtype);
+  d.addend_bits = (const uint8_t*)a->addend_bits;
+  d.addend_bits_ld = a->addend_bits_ld;
   return wide;
 }
 
@@ -2764,6 +2784,10 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
                  "conv: addend misaligned or addend_ld=%d < Cout=%d", a->addend_ld, a->Cout);
     SEGK_UNSUPPORTED(plan.ring && a->Cout % 128 == 0 && !a->bias && !a->img_bias && batch == 1,
                      "conv: an addend needs bf16 operands with 128-byte K rows, Cout a multiple of 128 and no biases");
+    SEGK_REQUIRE(!a->addend_bits || (long long)a->addend_bits_ld * 8 >= a->Cout, "conv: addend_bits_ld=%d < Cout / 8 (Cout=%d)",
+                 a->addend_bits_ld, a->Cout);
+  } else {
+    SEGK_REQUIRE(!a->addend_bits, "conv: addend_bits without an addend");
   }
   d.stat_batch = (long long)plan_stat_rows(d, plan) * 2 * d.Cout;
   hipStream_t st = (hipStream_t)stream;
@@ -2981,6 +3005,7 @@ extern "C" int segk_gemm_nt(const segk_gemm_args* a, segk_stream_t stream) {
   d.m_begin = 0; d.stat_row0 = 0;
   d.bias = nullptr; d.img_bias = nullptr; d.stat = nullptr;
   d.addend = nullptr; d.addend_ld_b = 0;
+  d.addend_bits = nullptr; d.addend_bits_ld = 0;
   const long long big_tiles = (long long)ceil_div(a->M, TileBig::BPX) * (a->N / TileBig::BCO) * a->batch;
   const bool big = wide && a->N % TileBig::BCO == 0 && big_tiles >= 512;
   static const char* gemm_env = experiment("SEGK_GEMM_DMA");

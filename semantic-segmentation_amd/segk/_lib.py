@@ -27,7 +27,7 @@ class ConvArgs(ctypes.Structure):
                 ("seg", ConvSeg * MAX_SEG), ("out", c_void_p), ("out_ld", c_int), ("out_dtype", c_int),
                 ("bias", c_void_p), ("img_bias", c_void_p), ("stat_partials", c_void_p), ("batch", c_int),
                 ("w_batch", c_ll), ("out_batch", c_ll), ("dil_step", c_int), ("addend", c_void_p),
-                ("addend_ld", c_int)]
+                ("addend_ld", c_int), ("addend_bits", c_void_p), ("addend_bits_ld", c_int)]
 
 
 class WgradArgs(ctypes.Structure):

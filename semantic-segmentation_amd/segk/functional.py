@@ -339,11 +339,12 @@ def unit_backward(rec, dz, need_dw=True, dw_like=None):
     return dy, dw, dgamma, dbeta
 
 
-def dgrad(items, geom, Cin, out_dtype, img_bias=None, addend=None):
+def dgrad(items, geom, Cin, out_dtype, img_bias=None, addend=None, addend_bits=None):
     """Data gradient of one or several convolutions that share their input: items = [(dy, weight, R, dil)].
     Returns a pixel-major [M, Cin rounded up to 4] tensor of out_dtype.  addend (a pixel-major view of out_dtype, or
     None): another gradient of the same input, added in the convolution's epilogue when the kernels can
-    (ops.conv_addend_ok) and by a separate addition otherwise - the same bits either way."""
+    (ops.conv_addend_ok) and by a separate addition otherwise - the same bits either way.  addend_bits (uint8
+    [M, Cin/8]): only the elements of the addend whose bit is set are added."""
     N, H, W = geom
     segs = []
     for dy, weight, R, dil in items:
@@ -352,10 +353,13 @@ def dgrad(items, geom, Cin, out_dtype, img_bias=None, addend=None):
     out = torch.empty((N * H * W, cpad), dtype=out_dtype, device=items[0][0].device)
     fused = addend is not None and img_bias is None and ops.conv_addend_ok(segs, Cin, out_dtype, addend)
     ops.conv_fwd(segs, N, H, W, Cin, out, img_bias=img_bias, true_ck=[it[1].shape[0] for it in items],
-                 addend=addend if fused else None)
+                 addend=addend if fused else None, addend_bits=addend_bits if fused else None)
     res = out[:, :Cin] if cpad != Cin else out
     if addend is not None and not fused:
-        res = res + addend[:, :Cin]
+        extra = addend[:, :Cin]
+        if addend_bits is not None:
+            extra = extra * ops.unpack_bits(addend_bits, Cin).to(extra.dtype)
+        res = res + extra
     return res
 
 
@@ -765,9 +769,13 @@ class SyncBNFunction(torch.autograd.Function):
                 gv = _vector_aligned(gv)   # the bit pattern is read by the 8-channel vector kernels only
             dx = torch.empty(shape, dtype=xv.dtype, device=g.device, memory_format=torch.channels_last)
             dxv = pm_view_of(dx)
-            if has_res:
+            # the consumer of the residual's gradient can mask the incoming gradient with the stored ReLU bits itself
+            lazy = (has_res and ctx.grad_slot is not None and ctx.needs_input_grad[5] and act is not None
+                    and act.dtype == torch.uint8 and relu)
+            if has_res and not lazy:
                 dres = torch.empty(shape, dtype=xv.dtype, device=g.device, memory_format=torch.channels_last)
         else:
+            lazy = False
             gv = g.to(xv.dtype).contiguous()
             dx = torch.empty_like(xv)
             dxv = dx
@@ -781,7 +789,9 @@ class SyncBNFunction(torch.autograd.Function):
             dx = dx.to(in_dtype)
         if not ctx.affine:
             dgamma = dbeta = None
-        if ctx.grad_slot is not None and dres is not None and ctx.needs_input_grad[5]:
+        if lazy:
+            ctx.grad_slot.put(gv, bits=act)
+        elif ctx.grad_slot is not None and dres is not None and ctx.needs_input_grad[5]:
             ctx.grad_slot.put(dres)
             dres = None
         return dx, dgamma, dbeta, None, None, dres, None
@@ -808,17 +818,22 @@ class GradSlot:
     conv1 and the shortcut: the function that produces the shortcut's gradient (it runs first in backward) leaves it
     here instead of returning it to autograd, and conv1's function adds it inside its data-gradient convolution, so
     x receives ONE gradient and autograd's separate addition of two 36 - 136 MB tensors per block disappears."""
-    __slots__ = ("grad",)
+    __slots__ = ("grad", "bits")
 
     def __init__(self):
-        self.grad = None
+        self.grad = self.bits = None
 
-    def put(self, g):
-        self.grad = g
+    def put(self, g, bits=None):
+        """g: the gradient (an NCHW-shaped channels_last tensor or its pixel-major view).  bits (uint8 [M, C/8], the
+        ReLU pattern of the block's last unit): the gradient is g where the bit is set and zero elsewhere - the
+        consumer applies the pattern, so the producer need not write a masked copy of g."""
+        self.grad, self.bits = g, bits
 
     def take(self):
-        g, self.grad = self.grad, None
-        return g
+        """-> (gradient or None, bit pattern or None)"""
+        g, b = self.grad, self.bits
+        self.grad = self.bits = None
+        return g, b
 
 
 # ------------------------------------------------- feeder conv + BN + ReLU ----
@@ -863,15 +878,22 @@ class ConvBNReLUFunction(torch.autograd.Function):
             dy, dw, dgamma, dbeta = unit_backward(rec, to_pm(g, rec.x.dtype), need_dw=ctx.needs_input_grad[1],
                                                   dw_like=rec.weight)
             dx = None
-            other = ctx.grad_slot.take() if ctx.grad_slot is not None else None
+            other, other_bits = ctx.grad_slot.take() if ctx.grad_slot is not None else (None, None)
             if ctx.needs_input_grad[0]:
                 gd = grad_dtype_for(x)
-                ov = pm_view_of(other) if other is not None else None
+                ov = None
+                if other is not None:
+                    ov = other if other.dim() == 2 else pm_view_of(other)
                 if other is not None and (ov is None or ov.dtype != gd):
-                    ov, late = None, other          # not a pixel-major tensor of the gradient's dtype: add afterwards
+                    # not a pixel-major tensor of the gradient's dtype: add afterwards
+                    late = other if other.dim() == 4 else grad_like(x, other, N, H, W)
+                    if other_bits is not None:
+                        keep = ops.unpack_bits(other_bits, rec.Cin).reshape(N, H, W, rec.Cin).permute(0, 3, 1, 2)
+                        late = late * keep.to(late.dtype)
+                    ov = other_bits = None
                 else:
                     late = None
-                dxp = dgrad([(dy, rec.weight, rec.R, rec.dil)], rec.geom, rec.Cin, gd, addend=ov)
+                dxp = dgrad([(dy, rec.weight, rec.R, rec.dil)], rec.geom, rec.Cin, gd, addend=ov, addend_bits=other_bits)
                 dx = grad_like(x, dxp, N, H, W)
                 if late is not None:
                     dx = dx + late.to(dx.dtype)
@@ -934,8 +956,12 @@ class ConvBNAddReLUFunction(torch.autograd.Function):
         dbeta, dgamma = dgb[0], dgb[1]
         gs = _global_sums(local, sync and training)
         dy = torch.empty_like(raw)
-        dres = torch.empty((N, Cout, H, W), dtype=raw.dtype, device=g.device, memory_format=torch.channels_last)
-        ops.bn_bwd_apply(gv, raw, dy, coef, gs, PM, True, eval_mode=not training, act=act, dres=pm_view_of(dres))
+        # the consumer of the residual's gradient can mask the incoming gradient with the stored ReLU bits itself
+        lazy = ctx.grad_slot is not None and ctx.needs_input_grad[4] and act.dtype == torch.uint8
+        dres = None if lazy else torch.empty((N, Cout, H, W), dtype=raw.dtype, device=g.device,
+                                             memory_format=torch.channels_last)
+        ops.bn_bwd_apply(gv, raw, dy, coef, gs, PM, True, eval_mode=not training, act=act,
+                         dres=pm_view_of(dres) if dres is not None else None)
         with ops.scoped("@feeder"):
             dw = None
             if ctx.needs_input_grad[1]:
@@ -944,7 +970,9 @@ class ConvBNAddReLUFunction(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dxp = dgrad([(dy, weight, R, dil)], geom, Cin, grad_dtype_for(x))
                 dx = grad_like(x, dxp, N, H, W)
-        if ctx.grad_slot is not None and ctx.needs_input_grad[4]:
+        if lazy:
+            ctx.grad_slot.put(gv, bits=act)
+        elif ctx.grad_slot is not None and ctx.needs_input_grad[4]:
             ctx.grad_slot.put(dres)
             dres = None
         return dx, dw, dgamma, dbeta, (dres if ctx.needs_input_grad[4] else None), None, None, None

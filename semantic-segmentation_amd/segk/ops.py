@@ -398,12 +398,13 @@ def weight_usable_in_place(w, R, Cout):
 
 
 def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=False, true_ck=None, batch=1,
-             dil_step=0, out_batch=0, addend=None):
+             dil_step=0, out_batch=0, addend=None, addend_bits=None):
     """segs: list of (in_view [M, >=Ck], packed_w [taps, Cout, Ck], R, dil); instead of a packed operand a segment
     may carry the nn.Conv2d weight itself when it is channels_last [Cout, Cin, R, R] of the operand dtype with Cin a
     multiple of 32 (used in place).  Writes `out` ([M, Cout'] view, Cout' >= Cout rounded up to 4).  Returns the [rows, 2, Cout] statistic partials when want_stats.
     true_ck: un-padded contracted channel counts per segment (only used for FLOP accounting).
-    addend: pixel-major view [M, >=Cout] of out's dtype: out = round(conv) + addend (see conv_addend_ok)."""
+    addend: pixel-major view [M, >=Cout] of out's dtype: out = round(conv) + addend (see conv_addend_ok);
+    addend_bits: uint8 [M, >=Cout/8] beside it, one bit per element: a clear bit adds zero instead."""
     M = N * H * W
     timer_ck = true_ck if true_ck is not None else [(w.shape[1] if w.dim() == 4 and batch <= 1 else w.shape[-1])
                                                     for _, w, _, _ in segs]
@@ -453,8 +454,16 @@ def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=Fals
         if addend.dtype != out.dtype or addend.shape[0] != M or ac < Cout:
             raise ValueError("the addend is a pixel-major view of the output's dtype with at least Cout channels")
         a.addend, a.addend_ld = addend.data_ptr(), ald
+        if addend_bits is not None:
+            _dev(addend_bits)
+            if addend_bits.dtype != torch.uint8 or addend_bits.dim() != 2 or not addend_bits.is_contiguous() \
+                    or addend_bits.shape[0] != M or addend_bits.shape[1] * 8 < Cout:
+                raise ValueError("addend_bits is a contiguous uint8 [M, >=Cout/8] tensor")
+            a.addend_bits, a.addend_bits_ld = addend_bits.data_ptr(), addend_bits.shape[1]
     else:
         a.addend, a.addend_ld = None, 0
+        if addend_bits is not None:
+            raise ValueError("addend_bits without an addend")
     if batch > 1:
         if len(segs) != 1 or bias is not None or img_bias is not None:
             raise ValueError("a batched convolution has one segment and no bias")
@@ -479,6 +488,13 @@ def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=Fals
                 inb += f * inbounds_fraction(H, W, segs[i][2], segs[i][3] + b * dil_step)
         TIMER.stop("conv_fwd_kernel", fl, t0, inbounds=inb)
     return stats
+
+
+def unpack_bits(bits, C):
+    """[M, C/8] uint8 bit pattern (bit c % 8 of byte c / 8) -> bool [M, C]: the slow, plain-PyTorch reading of what the
+    kernels consume directly; for fall-back paths only."""
+    shifts = torch.arange(8, device=bits.device, dtype=torch.uint8)
+    return ((bits.unsqueeze(-1) >> shifts) & 1).reshape(bits.shape[0], -1)[:, :C].bool()
 
 
 def conv_addend_ok(segs, Cout, out_dtype, addend):

@@ -152,6 +152,55 @@ def test_conv_multi_segment_is_sum(ops, dtype, tol):
     assert relerr(from_pm(out, N, H, W), ref) < tol
 
 
+# N, H, W, Cin, Cout, R, dil: 128 output channels = one narrow ring tile, 256 = the wide one, 512 = two of them
+ADDEND_CASES = [(2, 17, 15, 128, 256, 3, 2), (1, 33, 33, 256, 128, 1, 1), (2, 9, 11, 64, 512, 1, 1)]
+
+
+@pytest.mark.parametrize("case", ADDEND_CASES)
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shift", [0, 4])
+def test_conv_addend_and_bit_pattern(ops, case, out_dtype, shift):
+    """segk_conv_args.addend / addend_bits: the epilogue adds a second tensor to the ROUNDED convolution result (the
+    bits of a separate addition), all of it or only the elements whose bit is set in a [M, Cout/8] byte pattern
+    (the ReLU pattern of a bottleneck's last unit masking the shortcut's gradient).  shift = 4: output and addend
+    start four channels into wider buffers, which takes the epilogue's 4-channel store path."""
+    N, H, W, Cin, Cout, R, dil = case
+    M = N * H * W
+    x, w = _conv_inputs(case)
+    xv = to_pm(x, torch.bfloat16)[0]
+    wp = ops.pack_weight(w, torch.bfloat16)
+    plain = torch.empty((M, Cout), dtype=out_dtype, device=DEV)
+    ops.conv_fwd([(xv, wp, R, dil)], N, H, W, Cout, plain)
+    add_buf = T(gen.normal(13, "ad%s" % (case,), (M, Cout + 8)), out_dtype)
+    addend = add_buf[:, shift:shift + Cout]
+    bits = torch.from_numpy(gen.integers(13, "ab%s" % (case,), (M, Cout // 8), 0, 256).astype(np.uint8)).to(DEV)
+    out_buf = torch.full((M, Cout + 8), float("nan"), dtype=out_dtype, device=DEV)
+    out = out_buf[:, shift:shift + Cout]
+    assert ops.conv_addend_ok([(xv, wp, R, dil)], Cout, out_dtype, addend)
+    ops.conv_fwd([(xv, wp, R, dil)], N, H, W, Cout, out, addend=addend)
+    assert torch.equal(out, plain + addend)
+    out_buf.fill_(float("nan"))
+    ops.conv_fwd([(xv, wp, R, dil)], N, H, W, Cout, out, addend=addend, addend_bits=bits)
+    keep = ops.unpack_bits(bits, Cout)
+    assert torch.equal(out, plain + torch.where(keep, addend, torch.zeros_like(addend)))
+    assert bool(torch.isnan(out_buf[:, :shift]).all()) and bool(torch.isnan(out_buf[:, shift + Cout:]).all())
+    assert 0.3 < float(keep.float().mean()) < 0.7
+    with pytest.raises(ValueError):
+        ops.conv_fwd([(xv, wp, R, dil)], N, H, W, Cout, out, addend_bits=bits)
+
+
+def test_conv_addend_refused_off_the_ring_tile(ops):
+    N, H, W, Cin, Cout = 1, 9, 9, 64, 64      # 64 output channels: not a multiple of 128
+    x = T(gen.normal(13, "adr_x", (N, Cin, H, W)))
+    w = T(gen.normal(13, "adr_w", (Cout, Cin, 1, 1), std=0.05))
+    xv = to_pm(x, torch.bfloat16)[0]
+    wp = ops.pack_weight(w, torch.bfloat16)
+    out = torch.empty((N * H * W, Cout), dtype=torch.bfloat16, device=DEV)
+    assert not ops.conv_addend_ok([(xv, wp, 1, 1)], Cout, torch.bfloat16, out)
+    with pytest.raises(RuntimeError, match="addend"):
+        ops.conv_fwd([(xv, wp, 1, 1)], N, H, W, Cout, out, addend=torch.zeros_like(out))
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
 def test_conv_dgrad(ops, case, dtype, tol):
