@@ -68,7 +68,8 @@ def parse():
                     help="record the training iteration once as a HIP graph and replay it (auto: with one rank and the "
                          "HIP optimizer; ranks that exchange statistics and gradients issue their steps eagerly)")
     ap.add_argument("--overlap-wgrad", choices=["auto", "on", "off"], default="auto",
-                    help="segk.config.set_overlap_wgrad: weight gradients on a second HIP stream (auto: with --graph)")
+                    help="segk.config.set_overlap_wgrad: weight gradients taken off the backward chain and launched in "
+                         "groups (auto: with --graph); SEGK_WGRAD_SECOND_STREAM=1 puts them on a second HIP stream")
     ap.add_argument("--feeder-conv", choices=["auto", "hip", "torch"], default=None,
                     help="segk.config.set_feeder_conv: which kernels run the feeder's stride-1 3x3 convolutions of layers 2-4 "
                          "(default: the package default)")

@@ -7,6 +7,7 @@ import os
 
 _state = {"compute_dtype": torch.float32, "legacy_clamp_eps": False, "feeder_conv": "auto", "overlap_wgrad": False,
           "group_wgrad": os.environ.get("SEGK_GROUP_WGRAD", "1") != "0",
+          "wgrad_second_stream": os.environ.get("SEGK_WGRAD_SECOND_STREAM", "0") == "1",
           # debug switches (each costs a host synchronisation or an extra pass where it acts)
           "debug_packs": os.environ.get("SEGK_DEBUG_PACKS", "") == "1",
           "debug_labels": os.environ.get("SEGK_DEBUG_LABELS", "") == "1",
@@ -76,12 +77,12 @@ def feeder_conv_as(mode):
 
 
 def set_overlap_wgrad(flag):
-    """True: inside ``loss.backward()`` the weight gradients of the HIP convolution units run on a second HIP stream
-    beside the chain of data gradients and batch-norm backward passes (nothing but the optimizer waits for a weight
-    gradient; a matrix-bound launch beside memory-bound ones fills the chip better than either alone).  The
-    gradients are then written to ``weight.grad`` by an end-of-backward callback after the streams have joined,
-    not returned through autograd: use it with ``.backward()`` loops only (``torch.autograd.grad`` would see None
-    for those weights, and hooks on the weights do not fire).  Ignored while a segk.parallel.GradientBuckets with
+    """True: inside ``loss.backward()`` the weight gradients of the HIP convolution units are taken off the chain of
+    data gradients and batch-norm backward passes (nothing but the optimizer waits for a weight gradient): they are
+    queued, launched in groups of one shape (set_group_wgrad) and written to ``weight.grad`` by an end-of-backward
+    callback, not returned through autograd: use it with ``.backward()`` loops only (``torch.autograd.grad`` would see
+    None for those weights, and hooks on the weights do not fire).  Their launches go to the launching stream by
+    default and to a second HIP stream with set_wgrad_second_stream(True).  Ignored while a segk.parallel.GradientBuckets with
     overlap=True exists: its all-reduces are started from parameter hooks.  Default False."""
     _state["overlap_wgrad"] = bool(flag)
 
@@ -98,6 +99,29 @@ def overlap_wgrad_as(flag):
         yield
     finally:
         _state["overlap_wgrad"] = old
+
+
+def set_wgrad_second_stream(flag):
+    """True (or SEGK_WGRAD_SECOND_STREAM=1): deferred weight gradients (set_overlap_wgrad) run on a second HIP stream
+    beside the rest of the backward pass.  Default False: measured on MI355X the two streams only take compute units
+    from each other - every ring-tile kernel fills a CU's LDS and registers, so nothing co-resides with it, and the
+    memory-bound batch-norm launches run at 60 % of their speed beside a weight gradient - 24.61 against 24.91 ms per
+    step on one box once the weight gradients are grouped."""
+    _state["wgrad_second_stream"] = bool(flag)
+
+
+def wgrad_second_stream():
+    return _state["wgrad_second_stream"]
+
+
+@contextlib.contextmanager
+def wgrad_second_stream_as(flag):
+    old = _state["wgrad_second_stream"]
+    set_wgrad_second_stream(flag)
+    try:
+        yield
+    finally:
+        _state["wgrad_second_stream"] = old
 
 
 def set_group_wgrad(flag):

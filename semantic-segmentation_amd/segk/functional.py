@@ -204,8 +204,8 @@ def unit_finish(x, raw, stats, weight, R, dil, geom, spec, gamma, beta, out, rel
     return rec
 
 
-# ---- weight gradients beside the data-gradient chain (config.set_overlap_wgrad) -------------------------------
-_SIDE_STREAMS = {}   # device index -> the second stream
+# ---- weight gradients off the data-gradient chain (config.set_overlap_wgrad) -----------------------------------
+_SIDE_STREAMS = {}   # device index -> the second stream (config.set_wgrad_second_stream)
 _PENDING = []        # (weight, dW, main stream, side stream, tensors the side stream reads, backward pass id)
 _GROUPS = {}         # shape key -> _Group: gradients of one shape waiting for a launch together (config.group_wgrad)
 _CLOCK = [0, None]   # [weight_grad calls on the deferred path, backward pass id of everything queued]
@@ -226,11 +226,13 @@ def _backward_pass_id():
 
 
 def _launch_deferred(entries, args, pass_id):
-    """Start the weight gradients of `entries` = [(weight, x, dy, like, main, side)] (one shape, one device) on the
-    second stream, as one launch when there are several, and queue them for the join."""
+    """Start the weight gradients of `entries` = [(weight, x, dy, like, main, side)] (one shape, one device) on
+    `side` (the launching stream itself, or the second stream), as one launch when there are several, and queue them
+    for the join."""
     N, H, W, R, dil, Cout, Cin = args
     main, side = entries[0][4], entries[0][5]
-    side.wait_stream(main)
+    if side is not main:
+        side.wait_stream(main)
     with torch.cuda.stream(side):
         if len(entries) == 1:
             weight, x, dy, like = entries[0][:4]
@@ -264,7 +266,7 @@ def _join_weight_grads():
     del _PENDING[:]
     joined = set()
     for weight, dw, main, side, _, _ in pending:
-        if (main, side) not in joined:
+        if side is not main and (main, side) not in joined:
             main.wait_stream(side)
             joined.add((main, side))
     for weight, dw, main, side, _, _ in pending:
@@ -284,9 +286,11 @@ def weight_grad(weight, x, dy, N, H, W, R, dil, Cout, Cin, like=None):
     if not deferred:
         return ops.conv_wgrad(x, dy, N, H, W, R, dil, Cout, Cin, like=like)
     main = torch.cuda.current_stream(x.device)
-    side = _SIDE_STREAMS.get(x.device.index)
-    if side is None:
-        side = _SIDE_STREAMS[x.device.index] = torch.cuda.Stream(device=x.device)
+    side = main
+    if config.wgrad_second_stream():
+        side = _SIDE_STREAMS.get(x.device.index)
+        if side is None:
+            side = _SIDE_STREAMS[x.device.index] = torch.cuda.Stream(device=x.device)
     # (gradients left over from a backward pass that raised before its end-of-pass callback belong to no parameter
     # any more: they are dropped, not added to this pass's)
     pass_id = _backward_pass_id()

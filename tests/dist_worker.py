@@ -226,7 +226,7 @@ def run_mailbox(rank, world, outdir, gradients=True):
     gradient buckets), then five SGD iterations issued eagerly and the same five with the last three replayed from
     a HIP graph, with the cross-rank comparison of the statistics switched on for the eager ones.
     gradients=False: the buckets stay on torch.distributed (gloo here, RCCL in production); the replayed iteration
-    is then two graphs with the buckets' all-reduce between them, and its weight gradients run on the second stream."""
+    is then two graphs with the buckets' all-reduce between them, and its weight gradients are deferred and grouped."""
     from segk import config, parallel
     if world > 1:
         assert parallel.connect_mailboxes(timeout_ms=20000, gradients=gradients), parallel.exchange_description()

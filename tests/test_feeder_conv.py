@@ -299,10 +299,11 @@ def test_repeated_bottlenecks_weight_gradients_in_groups():
         sizes.append(len(xs))
         return real_group(xs, *a, **k)
 
-    def run(group, passes=1):
+    def run(group, passes=1, second=False):
         net.zero_grad(set_to_none=True)
         x = x0.clone().requires_grad_(True)
-        with config.overlap_wgrad_as(True), config.group_wgrad_as(group), mock.patch.object(ops, "conv_wgrad_group", counting):
+        with config.overlap_wgrad_as(True), config.group_wgrad_as(group), config.wgrad_second_stream_as(second), \
+                mock.patch.object(ops, "conv_wgrad_group", counting):
             for _ in range(passes):
                 with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
                     y = net(x)
@@ -320,6 +321,10 @@ def test_repeated_bottlenecks_weight_gradients_in_groups():
     for p, a, b in zip(net.parameters(), one_by_one, grouped):
         assert a.shape == b.shape == p.shape and a.dtype == b.dtype and a.stride() == b.stride()
         assert rel(b, a) < 1e-2, (tuple(p.shape), rel(b, a))   # one bf16 rounding step
+    # the same launches on a second stream: the same bits
+    _, on_second = run(True, second=True)
+    for a, b in zip(grouped, on_second):
+        assert torch.equal(a, b)
     gx2, twice = run(True, passes=2)
     for a, b in zip(grouped, twice):
         if a.dtype == torch.bfloat16:

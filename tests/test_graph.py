@@ -95,9 +95,10 @@ def deterministic_feeder():
     torch.use_deterministic_algorithms(False)
 
 
-@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("overlap", [False, True, "second stream"])
 def test_replayed_iterations_equal_eager_iterations(deterministic_feeder, overlap):
-    """overlap: weight gradients on the second stream inside the recorded iteration (what bench.py runs)."""
+    """overlap: weight gradients deferred inside the recorded iteration (what bench.py runs), on the launching stream
+    or on a second one."""
     from segk import config
     from segk.graph import GraphedTrainStep
     dev = "cuda:0"
@@ -127,7 +128,7 @@ def test_replayed_iterations_equal_eager_iterations(deterministic_feeder, overla
 
         opt2, crit2, sched2 = _trainer(replayed)
         sched2(opt2, 0, 0, 0.0)
-        with config.overlap_wgrad_as(overlap):
+        with config.overlap_wgrad_as(bool(overlap)), config.wgrad_second_stream_as(overlap == "second stream"):
             stepper = GraphedTrainStep(replayed, crit2, opt2, images[0], targets[0], warmup=2)
         got = []
         for i in range(2, 6):
@@ -162,10 +163,11 @@ def test_refuses_other_shapes_and_frozen_rates():
         stepper(x, y)
 
 
-def test_weight_gradients_on_second_stream_equal_inline(deterministic_feeder):
-    """config.set_overlap_wgrad: the head's weight gradients run on a second stream and reach weight.grad through the
-    end-of-backward callback.  Same kernels, same operands: every gradient equals the inline path bit for bit, also
-    when a second backward pass accumulates into existing gradients."""
+def test_deferred_weight_gradients_equal_inline(deterministic_feeder):
+    """config.set_overlap_wgrad: the head's weight gradients are launched off the chain (on the launching stream, or on
+    a second stream with config.set_wgrad_second_stream) and reach weight.grad through the end-of-backward callback.
+    Same kernels, same operands: every gradient equals the inline path bit for bit, also when a second backward pass
+    accumulates into existing gradients."""
     from segk import config
     from segk.utils.loss import SegmentationLosses
     dev = "cuda:0"
@@ -177,16 +179,19 @@ def test_weight_gradients_on_second_stream_equal_inline(deterministic_feeder):
 
     def grads(overlap):
         model = _small_model(21)
-        with config.feeder_conv_as("torch"), config.overlap_wgrad_as(overlap):
+        with config.feeder_conv_as("torch"), config.overlap_wgrad_as(bool(overlap)), \
+                config.wgrad_second_stream_as(overlap == "second stream"):
             for _ in range(2):   # the second pass adds to the first one's gradients
                 crit(model(image), target).backward()
         torch.cuda.synchronize()
         return {n: p.grad.detach().clone() for n, p in model.named_parameters()}
 
-    inline, overlapped = grads(False), grads(True)
-    assert inline.keys() == overlapped.keys()
-    for n in inline:
-        assert torch.equal(inline[n], overlapped[n]), n
+    inline = grads(False)
+    for mode in (True, "second stream"):
+        deferred = grads(mode)
+        assert inline.keys() == deferred.keys()
+        for n in inline:
+            assert torch.equal(inline[n], deferred[n]), (mode, n)
 
 
 def test_recorded_step_survives_another_optimizer(deterministic_feeder):
