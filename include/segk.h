@@ -344,6 +344,16 @@ int segk_dropout_mask(uint8_t* mask, long long n, float p, const long long* seed
  * scale * sum_pixels x[n][p][c]  (scale = 1/HW forward; 1 to sum a gradient). */
 int segk_pool_sum(const void* x, int dtype, int ld, int N, int HW, int C, float scale, float* out,
                   segk_stream_t stream);
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the ResNet stem (newmodeling/backbone/resnet101_2.py:79,149) on a
+ * pixel-major tensor [N*Hi*Wi][x_ld] -> [N*Ho*Wo][y_ld], Ho = (Hi - 1) / 2 + 1.  idx ([N*Ho*Wo][C] bytes) receives the
+ * position of the maximum inside its window (0..8; the first maximum in scan order, a NaN is a maximum: ATen's rule);
+ * the backward pass gathers with it: dx[p] = sum of dy over the (at most four) windows whose maximum is p, added in
+ * ascending window order in fp32.  C a multiple of 8, 16-byte aligned operands, leading dimensions multiples of 8:
+ * SEGK_UNSUPPORTED_SHAPE otherwise. */
+int segk_maxpool3x3s2_fwd(const void* x, int dtype, int x_ld, int N, int C, int Hi, int Wi, void* y, int y_ld,
+                          uint8_t* idx, segk_stream_t stream);
+int segk_maxpool3x3s2_bwd(const void* dy, int dtype, int dy_ld, const uint8_t* idx, int N, int C, int Hi, int Wi,
+                          void* dx, int dx_ld, segk_stream_t stream);
 /* F.interpolate(mode='bilinear', align_corners=True) (modeling/aspp.py:137, modeling/decoder.py:176,
  * modeling/deeplab.py:252).  Source is pixel-major [N*Hi*Wi][in_ld]; the destination is pixel-major
  * (out_layout = SEGK_PM, [N*Ho*Wo][out_ld], out_dtype) or NCHW fp32 (out_layout = SEGK_NCHW). */

@@ -430,6 +430,95 @@ __global__ __launch_bounds__(256) void upsample_bwd_cols_kernel(const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------
+// nn.MaxPool2d(kernel_size=3, stride=2, padding=1) on pixel-major tensors (the ResNet stem).  Forward keeps the
+// position of the maximum inside its window (0..8, one byte per element) instead of a 64-bit flat index; backward is
+// a gather: an input pixel belongs to at most four windows (one per coordinate when the coordinate is even, two when
+// it is odd) and adds the gradient of those whose stored position points at it, in ascending window order.
+// The first maximum in scan order wins and a NaN is a maximum, as in ATen.  thread = (pixel, group of 8 channels).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3x3s2_fwd_kernel(const T* __restrict__ x, int x_ld, int C, int Hi, int Wi,
+                                                                T* __restrict__ y, int y_ld, uint8_t* __restrict__ idx,
+                                                                int Ho, int Wo, long long total) {
+  const int cg = C >> 3;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long pix = i / cg;
+    const int c0 = (int)(i - pix * cg) * 8;
+    const int ox = (int)(pix % Wo);
+    const long long t = pix / Wo;
+    const int oy = (int)(t % Ho);
+    const long long n = t / Ho;
+    const T* b = x + (size_t)n * Hi * Wi * x_ld + c0;
+    float best[8];
+    unsigned pos[8];
+    bool first = true;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = 2 * oy - 1 + ky;
+      if (iy < 0 || iy >= Hi) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = 2 * ox - 1 + kx;
+        if (ix < 0 || ix >= Wi) continue;
+        float v[8];
+        loadv<T, 8>(b + ((size_t)iy * Wi + ix) * x_ld, v);
+        const unsigned k = ky * 3 + kx;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          // the first position of the window holds the index until something is greater than -inf (or a NaN)
+          if (first) { best[j] = -INFINITY; pos[j] = k; }
+          if (v[j] > best[j] || v[j] != v[j]) { best[j] = v[j]; pos[j] = k; }
+        }
+        first = false;
+      }
+    }
+    storev<T, 8>(y + (size_t)pix * y_ld + c0, best);
+    u32x2 packed = {pos[0] | (pos[1] << 8) | (pos[2] << 16) | (pos[3] << 24), pos[4] | (pos[5] << 8) | (pos[6] << 16) | (pos[7] << 24)};
+    *reinterpret_cast<u32x2*>(idx + (size_t)pix * C + c0) = packed;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const T* __restrict__ dy, int dy_ld, const uint8_t* __restrict__ idx,
+                                                                int C, int Hi, int Wi, T* __restrict__ dx, int dx_ld,
+                                                                int Ho, int Wo, long long total) {
+  const int cg = C >> 3;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long pix = i / cg;
+    const int c0 = (int)(i - pix * cg) * 8;
+    const int ix = (int)(pix % Wi);
+    const long long t = pix / Wi;
+    const int iy = (int)(t % Hi);
+    const long long n = t / Hi;
+    // windows that contain row iy: oy = iy / 2 with ky = 1 for an even row; (iy - 1) / 2 with ky = 2, then
+    // (iy + 1) / 2 with ky = 0 for an odd one (ascending oy); the same along x
+    const int ny = (iy & 1) ? 2 : 1, nx = (ix & 1) ? 2 : 1;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int a = 0; a < ny; ++a) {
+      const int oy = (iy & 1) ? (a == 0 ? (iy - 1) / 2 : (iy + 1) / 2) : iy / 2;
+      const int ky = (iy & 1) ? (a == 0 ? 2 : 0) : 1;
+      if (oy >= Ho) continue;
+      for (int bq = 0; bq < nx; ++bq) {
+        const int ox = (ix & 1) ? (bq == 0 ? (ix - 1) / 2 : (ix + 1) / 2) : ix / 2;
+        const int kx = (ix & 1) ? (bq == 0 ? 2 : 0) : 1;
+        if (ox >= Wo) continue;
+        const size_t op = ((size_t)n * Ho + oy) * Wo + ox;
+        const u32x2 pk = *reinterpret_cast<const u32x2*>(idx + op * C + c0);
+        float g[8];
+        loadv<T, 8>(dy + op * dy_ld + c0, g);
+        const unsigned k = ky * 3 + kx;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (((pk[j >> 2] >> (8 * (j & 3))) & 0xffu) == k) acc[j] += g[j];
+      }
+    }
+    storev<T, 8>(dx + (size_t)pix * dx_ld + c0, acc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Final upsample fused with the cross entropy: the full-resolution logits are never written.
 //   forward : thread per output pixel interpolates its K logits from the four source pixels (pixel-major fp32,
 //             cache resident: 2 MB per image), log-sum-exp on the fly, NLL of the label.
@@ -816,5 +905,44 @@ extern "C" int segk_upsample_argmax(const float* low, int low_ld, int N, int K, 
   upsample_argmax_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(low, low_ld, K, Hi, Wi, Ho, Wo, P, host_scale(Hi, Ho),
                                                                       host_scale(Wi, Wo), pred);
   SEGK_CHECK_LAUNCH("upsample_argmax");
+  return SEGK_OK;
+}
+
+static int maxpool_check(const char* name, int N, int C, int Hi, int Wi, std::initializer_list<const void*> ptrs,
+                         std::initializer_list<int> lds, int dtype) {
+  SEGK_REQUIRE(N > 0 && C > 0 && Hi > 0 && Wi > 0 && valid_dtype(dtype), "%s: bad shape or dtype", name);
+  bool ok = C % 8 == 0;
+  for (const void* p : ptrs) ok = ok && p != nullptr && aligned_to(p, 16);
+  for (int ld : lds) ok = ok && ld % 8 == 0 && ld >= C;
+  SEGK_UNSUPPORTED(ok, "%s: needs C %% 8 == 0 (C=%d), 16-byte aligned operands and leading dimensions that are multiples of 8",
+                   name, C);
+  return SEGK_OK;
+}
+
+extern "C" int segk_maxpool3x3s2_fwd(const void* x, int dtype, int x_ld, int N, int C, int Hi, int Wi, void* y, int y_ld,
+                                     uint8_t* idx, segk_stream_t stream) {
+  int rc = maxpool_check("maxpool_fwd", N, C, Hi, Wi, {x, y, idx}, {x_ld, y_ld}, dtype);
+  if (rc != SEGK_OK) return rc;
+  const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
+  const long long total = (long long)N * Ho * Wo * (C / 8);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  SEGK_DISPATCH_DTYPE(dtype, T, (maxpool3x3s2_fwd_kernel<T><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(
+      (const T*)x, x_ld, C, Hi, Wi, (T*)y, y_ld, idx, Ho, Wo, total)));
+  SEGK_CHECK_LAUNCH("maxpool_fwd");
+  return SEGK_OK;
+}
+
+extern "C" int segk_maxpool3x3s2_bwd(const void* dy, int dtype, int dy_ld, const uint8_t* idx, int N, int C, int Hi, int Wi,
+                                     void* dx, int dx_ld, segk_stream_t stream) {
+  int rc = maxpool_check("maxpool_bwd", N, C, Hi, Wi, {dy, dx, idx}, {dy_ld, dx_ld}, dtype);
+  if (rc != SEGK_OK) return rc;
+  const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
+  const long long total = (long long)N * Hi * Wi * (C / 8);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  SEGK_DISPATCH_DTYPE(dtype, T, (maxpool3x3s2_bwd_kernel<T><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(
+      (const T*)dy, dy_ld, idx, C, Hi, Wi, (T*)dx, dx_ld, Ho, Wo, total)));
+  SEGK_CHECK_LAUNCH("maxpool_bwd");
   return SEGK_OK;
 }

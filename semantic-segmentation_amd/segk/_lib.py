@@ -140,6 +140,8 @@ SIGNATURES = {
     "segk_mailbox_allreduce_f64": [c_void_p, c_ll, c_void_p],
     "segk_mailbox_allreduce_f32": [c_void_p, c_ll, c_void_p],
     "segk_mailbox_status": [],
+    "segk_maxpool3x3s2_fwd": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p],
+    "segk_maxpool3x3s2_bwd": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p],
     "segk_mailbox_set_timeout": [c_int],
     "segk_dropout_mask": [c_void_p, c_ll, c_float, c_void_p, c_void_p],
     "segk_mailbox_destroy": [],

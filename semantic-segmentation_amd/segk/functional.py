@@ -608,6 +608,34 @@ def interpolate_bilinear_ac(x, size):
     return UpsampleFunction.apply(x, size)
 
 
+class MaxPool3x3S2Function(torch.autograd.Function):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) on a channels_last tensor (the ResNet stem,
+    newmodeling/backbone/resnet101_2.py:79,149): one byte of window position per output element instead of a 64-bit
+    index, and a gathering backward pass."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, C, H, W = x.shape
+        y, idx = ops.maxpool3x3s2(pm_view_of(x), N, H, W)
+        ctx.idx, ctx.dims = idx, (N, C, H, W)
+        return nchw_view_of(y, N, (H - 1) // 2 + 1, (W - 1) // 2 + 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, H, W = ctx.dims
+        gv = pm_view_of(g)
+        if not ops.maxpool3x3s2_ok(gv):
+            gv = pm_view_of(g.contiguous(memory_format=torch.channels_last))
+        return nchw_view_of(ops.maxpool3x3s2_bwd(gv, ctx.idx, N, C, H, W), N, H, W)
+
+
+def maxpool3x3s2(x):
+    """The HIP form when x is a channels_last fp32 / bf16 tensor the kernels take, None otherwise."""
+    if x.dim() != 4 or not ops.maxpool3x3s2_ok(pm_view_of(x)):
+        return None
+    return MaxPool3x3S2Function.apply(x)
+
+
 # ------------------------------------------------------------------- loss ----
 def _check_labels(target, K, ignore_index):
     """config.debug_labels: labels that are neither the ignore index nor a class index raise (the reference fails

@@ -25,6 +25,21 @@ def _bn_relu(bn, relu, x):
     return fused(x) if fused is not None else relu(bn(x))
 
 
+def _maxpool(pool, x):
+    """pool(x); the stem's 3 x 3 / stride 2 / padding 1 pooling of a channels_last GPU tensor runs on the HIP kernels
+    (one byte of window position per element instead of ATen's 64-bit indices)."""
+    if (isinstance(pool, nn.MaxPool2d) and pool.kernel_size in (3, (3, 3)) and pool.stride in (2, (2, 2))
+            and pool.padding in (1, (1, 1)) and pool.dilation in (1, (1, 1)) and not pool.ceil_mode
+            and not pool.return_indices and x.is_cuda and __package__):
+        # (this file is also loaded by path, outside the package, as the feeder of the plain-PyTorch restatement the
+        # tests compare against: there it stays on ATen)
+        from ... import functional as SF
+        y = SF.maxpool3x3s2(x)
+        if y is not None:
+            return y
+    return pool(x)
+
+
 def _conv(cin, cout, k, stride=1, dilation=1):
     pad = dilation if k == 3 else (3 if k == 7 else 0)
     return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=pad, dilation=dilation, bias=False)
@@ -122,7 +137,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*blocks)
 
     def forward(self, input):
-        x = self.maxpool(_bn_relu(self.bn1, self.relu, self.conv1(input)))
+        x = _maxpool(self.maxpool, _bn_relu(self.bn1, self.relu, self.conv1(input)))
         low_level_feat = self.layer1(x)
         x = self.layer4(self.layer3(self.layer2(low_level_feat)))
         return x, low_level_feat

@@ -1023,6 +1023,39 @@ def dropout_mask(shape, p, device):
 
 
 # ------------------------------------------------------- pooling / resample ----
+def maxpool3x3s2_ok(v):
+    """Whether maxpool3x3s2 takes the pixel-major view v: channels a multiple of 8, 16-byte aligned rows."""
+    return (v is not None and v.is_cuda and v.dim() == 2 and v.stride(1) == 1 and v.dtype in (torch.float32, torch.bfloat16)
+            and v.shape[1] % 8 == 0 and v.stride(0) % 8 == 0 and v.data_ptr() % 16 == 0)
+
+
+def maxpool3x3s2(x, N, H, W):
+    """nn.MaxPool2d(3, 2, 1) of the pixel-major view x [N*H*W, C] -> (y [N*Ho*Wo, C], idx uint8 [N*Ho*Wo, C] = position
+    of each maximum inside its window), Ho = (H - 1) // 2 + 1."""
+    _dev(x)
+    ld, C = _pm(x)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((N * Ho * Wo, C), dtype=x.dtype, device=x.device)
+    idx = torch.empty((N * Ho * Wo, C), dtype=torch.uint8, device=x.device)
+    t0 = _hbm_start()
+    call("segk_maxpool3x3s2_fwd", _ptr(x), _dt(x), ld, N, C, H, W, _ptr(y), C, _ptr(idx), _stream())
+    _hbm_stop("maxpool_fwd", _nbytes(x, y, idx), t0)
+    return y, idx
+
+
+def maxpool3x3s2_bwd(dy, idx, N, C, H, W):
+    """Gradient of maxpool3x3s2: dy [N*Ho*Wo, C] (pixel-major view) -> dx [N*H*W, C] of dy's dtype."""
+    _dev(dy, idx)
+    ld, c = _pm(dy)
+    if c != C or idx.shape != (dy.shape[0], C) or not idx.is_contiguous():
+        raise ValueError("gradient %s / positions %s do not belong to %d channels" % (tuple(dy.shape), tuple(idx.shape), C))
+    dx = torch.empty((N * H * W, C), dtype=dy.dtype, device=dy.device)
+    t0 = _hbm_start()
+    call("segk_maxpool3x3s2_bwd", _ptr(dy), _dt(dy), ld, _ptr(idx), N, C, H, W, _ptr(dx), C, _stream())
+    _hbm_stop("maxpool_bwd", _nbytes(dy, idx, dx), t0)
+    return dx
+
+
 def pool_sum(x, N, HW, scale):
     """x: pixel-major view [N*HW, C] -> [N, C] float32 = scale * sum over the pixels of each image."""
     _dev(x)

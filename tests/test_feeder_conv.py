@@ -336,3 +336,44 @@ def test_repeated_bottlenecks_weight_gradients_in_groups():
     assert len(sizes) == 0 or max(sizes) < 5, sizes
     for a, b in zip(one_by_one, early):
         assert rel(b, a) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 64, 33, 35), (1, 8, 6, 7), (3, 16, 1, 9), (2, 24, 16, 2)])
+def test_stem_maxpool_equals_aten(dtype, shape):
+    """nn.MaxPool2d(3, 2, 1) of the ResNet stem (newmodeling/backbone/resnet101_2.py:79) on the HIP kernels against
+    ATen on the same channels_last tensor: the same values, and the same input gradient bit for bit (the first maximum
+    of a window takes its gradient; windows are added in ascending order).  The input is a ReLU output with repeated
+    values, so windows of equal values (all zero, or tied maxima) are covered; odd and even sizes, a one-row map."""
+    from segk import functional as SF
+    dev = "cuda"
+    N, C, H, W = shape
+    g0 = torch.Generator().manual_seed(H * 100 + W)
+    x = (torch.randn(N, C, H, W, generator=g0).relu() * 4).round() / 4      # quarter steps: many ties, many zeros
+    x = x.to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    x1 = x.clone().requires_grad_(True)
+    x2 = x.clone().requires_grad_(True)
+    y1 = SF.maxpool3x3s2(x1)
+    assert y1 is not None
+    y2 = F.max_pool2d(x2, 3, 2, 1)
+    assert y1.shape == y2.shape and torch.equal(y1, y2)
+    gy = torch.randn(y2.shape, generator=g0).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    y1.backward(gy)
+    y2.backward(gy)
+    assert torch.equal(x1.grad, x2.grad)
+    # a gradient that is not channels_last is taken as well
+    x3 = x.clone().requires_grad_(True)
+    SF.maxpool3x3s2(x3).backward(gy.contiguous())
+    assert torch.equal(x3.grad, x2.grad)
+    # NaN is a maximum
+    xn = x.clone()
+    xn[0, 0, 0, 0] = float("nan")
+    assert torch.equal(torch.isnan(SF.maxpool3x3s2(xn)), torch.isnan(F.max_pool2d(xn, 3, 2, 1)))
+
+
+def test_stem_maxpool_declines_other_layouts():
+    from segk import functional as SF
+    x = torch.randn(2, 64, 9, 9, device="cuda")                    # NCHW-contiguous: no pixel-major view
+    assert SF.maxpool3x3s2(x) is None
+    x = torch.randn(2, 12, 9, 9, device="cuda").contiguous(memory_format=torch.channels_last)   # 12 channels
+    assert SF.maxpool3x3s2(x) is None
