@@ -373,7 +373,10 @@ def main():
         # eagerly and the buckets' all-reduces start from parameter hooks, under the backward pass.
         use_graph = args.optimizer == "hip" and args.graph != "off" and (
             world == 1 or parallel.step_is_capturable() or parallel.mailbox_active())
+        # recorded iterations exchange the buckets between two graphs, not under the backward pass: one large
+        # all-reduce then beats eight of 32 MB (2 (N - 1) ring steps of latency each)
         buckets = parallel.GradientBuckets([p for g in opt.param_groups for p in g["params"]],
+                                           bucket_mb=512.0 if use_graph else 32.0,
                                            overlap=world > 1 and args.optimizer == "hip" and not use_graph)
         config.set_overlap_wgrad(args.overlap_wgrad == "on" or (args.overlap_wgrad == "auto" and use_graph))
 
