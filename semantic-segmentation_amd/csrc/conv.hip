@@ -2174,6 +2174,101 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// A 1 x 1 convolution over a handful of rows (fp32): the ASPP image-pooling branch, whose "pixels" are the N pooled
+// vectors of the batch (modeling/aspp.py:121-123) - 16 rows x 2048 channels onto 256.  The implicit-GEMM tiles give
+// such a problem two workgroups that walk 64 K steps one after the other (160 us for 17 MFLOP).  Here a workgroup owns
+// four output channels for all rows, its 256 threads split K (float4 per thread and trip), and the partial sums meet
+// in a fixed order: lanes by a butterfly, wavefronts in index order.  Statistics (one partial row) and bias as in
+// the tiles' epilogue.  M <= SMALL_ROWS_MAX.
+// ------------------------------------------------------------------------------------------------
+constexpr int SMALL_ROWS_MAX = 32, SMALL_ROWS_CO = 4;
+
+template <typename TO>
+__global__ __launch_bounds__(256) void conv_small_rows_kernel(const ConvDev p) {
+  constexpr int RG = 16;                                 // rows per pass
+  __shared__ float part[4][RG * SMALL_ROWS_CO];
+  __shared__ float vals[RG * SMALL_ROWS_CO];
+  const SegDev& sg = p.seg[0];
+  const int co0 = blockIdx.x * SMALL_ROWS_CO;
+  const int K = sg.ck_b >> 2, M = (int)p.M;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* wrow[SMALL_ROWS_CO];
+#pragma unroll
+  for (int c = 0; c < SMALL_ROWS_CO; ++c)
+    wrow[c] = reinterpret_cast<const float*>(sg.w + (size_t)(co0 + c < p.Cout ? co0 + c : p.Cout - 1) * sg.w_ld_b);
+  double s1 = 0.0, s2 = 0.0;                              // threads 0..3: statistics of channel co0 + threadIdx.x
+  for (int m0 = 0; m0 < M; m0 += RG) {
+    float acc[RG][SMALL_ROWS_CO];
+#pragma unroll
+    for (int r = 0; r < RG; ++r)
+#pragma unroll
+      for (int c = 0; c < SMALL_ROWS_CO; ++c) acc[r][c] = 0.f;
+    for (int k = threadIdx.x * 4; k < K; k += 1024) {
+      f32x4 wv[SMALL_ROWS_CO];
+#pragma unroll
+      for (int c = 0; c < SMALL_ROWS_CO; ++c) wv[c] = *reinterpret_cast<const f32x4*>(wrow[c] + k);
+#pragma unroll
+      for (int r = 0; r < RG; ++r) {
+        const int m = m0 + r < M ? m0 + r : M - 1;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(sg.in + (size_t)m * sg.in_ld_b + (size_t)k * 4);
+#pragma unroll
+        for (int c = 0; c < SMALL_ROWS_CO; ++c)
+          acc[r][c] = fmaf(xv[3], wv[c][3], fmaf(xv[2], wv[c][2], fmaf(xv[1], wv[c][1], fmaf(xv[0], wv[c][0], acc[r][c]))));
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RG; ++r)
+#pragma unroll
+      for (int c = 0; c < SMALL_ROWS_CO; ++c) {
+        float v = acc[r][c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) part[wave][r * SMALL_ROWS_CO + c] = v;
+      }
+    __syncthreads();
+    if (threadIdx.x < RG * SMALL_ROWS_CO) {
+      const int r = threadIdx.x / SMALL_ROWS_CO, c = threadIdx.x - r * SMALL_ROWS_CO;
+      const int m = m0 + r, co = co0 + c;
+      float v = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+      vals[threadIdx.x] = m < M ? v : 0.f;               // the statistics see the convolution alone, as in the tiles
+      if (m < M && co < p.Cout) {
+        if (p.bias) v += p.bias[co];
+        if (p.img_bias) v += p.img_bias[(size_t)(m / p.HW) * p.Cout + co];
+        Elem<TO>::store(reinterpret_cast<TO*>(p.out) + (size_t)m * p.out_ld + co, v);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < SMALL_ROWS_CO) {
+#pragma unroll
+      for (int r = 0; r < RG; ++r) {
+        const double t = (double)vals[r * SMALL_ROWS_CO + threadIdx.x];
+        s1 += t;
+        s2 = fma(t, t, s2);
+      }
+    }
+    __syncthreads();
+  }
+  if (p.stat && threadIdx.x < SMALL_ROWS_CO && co0 + (int)threadIdx.x < p.Cout) {
+    p.stat[co0 + threadIdx.x] = s1;
+    p.stat[p.Cout + co0 + threadIdx.x] = s2;
+  }
+  // output columns between Cout and Cout rounded up to 4 are zero, as the tiles leave them
+  if (blockIdx.x == 0) {
+    const int cpad = (p.Cout + 3) & ~3;
+    for (int i = threadIdx.x; i < M * (cpad - p.Cout); i += 256) {
+      const int m = i / (cpad - p.Cout), c = p.Cout + i % (cpad - p.Cout);
+      Elem<TO>::store(reinterpret_cast<TO*>(p.out) + (size_t)m * p.out_ld + c, 0.f);
+    }
+  }
+}
+
+// the problems conv_small_rows_kernel takes
+static bool small_rows_problem(const segk_conv_args* a) {
+  return a->dtype == SEGK_F32 && a->nseg == 1 && a->seg[0].R == 1 && (long long)a->N * a->H * a->W <= SMALL_ROWS_MAX &&
+         a->batch <= 1 && !a->addend && a->seg[0].Ck % 4 == 0;
+}
+
 static int cu_count() {
   static int n = [] {
     int dev = 0, v = 0;
@@ -2763,6 +2858,7 @@ static bool fill_dev(const segk_conv_args* a, ConvDev& d) {
 extern "C" int segk_conv_stat_rows(const segk_conv_args* a) {
   if (!a || a->N <= 0 || a->H <= 0 || a->W <= 0 || a->nseg < 1 || a->nseg > SEGK_MAX_SEG || !valid_dtype(a->dtype))
     return SEGK_INVALID_ARG;
+  if (small_rows_problem(a)) return 1;
   ConvDev d;
   const bool wide = fill_dev(a, d);
   return plan_stat_rows(d, plan_tiles(d, wide, a->batch > 1 ? a->batch : 1, a->dtype == SEGK_BF16));
@@ -2776,6 +2872,13 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
   const int batch = a->batch > 1 ? a->batch : 1;
   SEGK_REQUIRE(batch <= 65535 && (batch == 1 || (!a->bias && !a->img_bias)),
                "conv: batch=%d (biases are not batched)", batch);
+  if (small_rows_problem(a)) {
+    const unsigned blocks = (unsigned)ceil_div(a->Cout, SMALL_ROWS_CO);
+    if (a->out_dtype == SEGK_BF16) conv_small_rows_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>(d);
+    else conv_small_rows_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>(d);
+    SEGK_CHECK_LAUNCH("conv_fwd");
+    return SEGK_OK;
+  }
   const TilePlan plan = plan_tiles(d, wide, batch, a->dtype == SEGK_BF16);
   const bool big = plan.big;
   if (a->addend) {

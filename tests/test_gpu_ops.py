@@ -201,6 +201,35 @@ def test_conv_addend_refused_off_the_ring_tile(ops):
         ops.conv_fwd([(xv, wp, 1, 1)], N, H, W, Cout, out, addend=torch.zeros_like(out))
 
 
+@pytest.mark.parametrize("rows", [(1, 1, 1), (16, 1, 1), (4, 2, 4), (3, 1, 9)])
+@pytest.mark.parametrize("cin,cout", [(2048, 256), (256, 2048), (96, 21)])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_conv_1x1_over_a_handful_of_rows(ops, rows, cin, cout, out_dtype):
+    """The ASPP image-pooling branch (modeling/aspp.py:121-123): a 1 x 1 convolution whose "pixels" are the N pooled
+    vectors.  fp32 problems of at most 32 rows take a kernel of their own (four output channels per workgroup, K split
+    over its threads): values, bias and the statistic partials (one row) against plain PyTorch."""
+    N, H, W = rows
+    M = N * H * W
+    x = T(gen.normal(14, "sr_x%s%d" % (rows, cin), (N, cin, H, W)))
+    w = T(gen.normal(14, "sr_w%d_%d" % (cin, cout), (cout, cin, 1, 1), std=(1.0 / cin) ** 0.5))
+    bias = T(gen.normal(14, "sr_b%d" % cout, (cout,)))
+    xv = to_pm(x, torch.float32, ld=ops.round_up(cin, 32))[1]
+    wp = ops.pack_weight(w, torch.float32)
+    cpad = ops.round_up(cout, 4)
+    out = torch.full((M, cpad + 4), float("nan"), dtype=out_dtype, device=DEV)
+    stats = ops.conv_fwd([(xv, wp, 1, 1)], N, H, W, cout, out[:, :cpad], want_stats=True, true_ck=[cin])
+    ref = F.conv2d(x.double(), w.double())
+    refpm = ref.permute(0, 2, 3, 1).reshape(M, cout)
+    tol = 2e-5 if out_dtype == torch.float32 else 1e-2
+    assert relerr(out[:, :cout], refpm) < tol
+    assert bool((out[:, cout:cpad] == 0).all()) and bool(torch.isnan(out[:, cpad:]).all())
+    assert tuple(stats.shape) == (1, 2, cout)
+    assert relerr(stats[0, 0], refpm.sum(0)) < 1e-5 and relerr(stats[0, 1], (refpm * refpm).sum(0)) < 1e-5
+    out2 = torch.empty((M, cpad), dtype=out_dtype, device=DEV)
+    ops.conv_fwd([(xv, wp, 1, 1)], N, H, W, cout, out2, bias=bias, true_ck=[cin])
+    assert relerr(out2[:, :cout], refpm + bias.double()) < tol
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
 def test_conv_dgrad(ops, case, dtype, tol):
