@@ -434,9 +434,18 @@ class ASPPFunction(torch.autograd.Function):
             # 274 tiles per branch need to fill 256 CUs), outputs side by side in one fp32 buffer
             ws = [params[3 * b] for b in (1, 2, 3)]
             Ck = ops.round_up(Cin, 32)
-            wp3 = torch.empty((3, 9, P, Ck), dtype=cd, device=x.device)
+            # the three operands side by side in a buffer the module keeps: weights registered with
+            # ops.cache_weight_packs (segk.optim.SGD does that) are then packed once and renewed by the optimizer's
+            # launch, like every other kept operand
+            wp3 = getattr(mod, "_segk_ladder_pack", None)
+            if wp3 is None or tuple(wp3.shape) != (3, 9, P, Ck) or wp3.dtype != cd or wp3.device != x.device:
+                if torch.cuda.is_current_stream_capturing():
+                    wp3 = torch.empty((3, 9, P, Ck), dtype=cd, device=x.device)
+                else:
+                    wp3 = mod._segk_ladder_pack = torch.empty((3, 9, P, Ck), dtype=cd, device=x.device)
+            keep = wp3 is getattr(mod, "_segk_ladder_pack", None)
             for i, w in enumerate(ws):
-                ops.pack_weight(w.detach(), cd, out=wp3[i])
+                ops.pack_weight(w.detach(), cd, out=wp3[i], keep=keep)
             raw3 = torch.empty((M, 3 * P), dtype=torch.float32, device=x.device)
             training = branches[1].bn.training or branches[1].bn.running_mean is None
             stats3 = ops.conv_fwd([(xp, wp3, 3, dils[1])], N, H, W, P, raw3[:, :P], want_stats=training,

@@ -333,18 +333,20 @@ def _check_kept_pack(w, entry, dtype, transpose):
                            % (tuple(w.shape),))
 
 
-def pack_weight(w, dtype, transpose=False, out=None):
+def pack_weight(w, dtype, transpose=False, out=None, keep=False):
     """nn.Conv2d weight [Cout,Cin,R,R] (fp32 or bf16; contiguous or channels_last) -> [taps, rows, Ck] operand
     (see segk_pack_weight); `out` may be a contiguous slice of a larger buffer of that shape.  Without `out`, a
     weight registered with cache_weight_packs gets its kept operand (packed again only if the weight's version
-    counter moved)."""
+    counter moved).  keep=True with `out`: that slice IS the kept operand of a registered weight (a caller that
+    needs several operands side by side owns the buffer and keeps it alive): nothing is packed while the weight's
+    version stands, and repack_cached_weights renews the slice in place."""
     _dev(w)
     if w.dtype not in (torch.float32, torch.bfloat16):
         raise ValueError("weights are float32 or bfloat16")
     Cout, Cin, R, S = w.shape
     dense = w.is_contiguous() or w.is_contiguous(memory_format=torch.channels_last)
     entry = None
-    if out is None and dense and _PACKS.params:
+    if (out is None or keep) and dense and _PACKS.params:
         owner, oid = _PACKS.owner(w)
         if owner is not None:
             key = (w.data_ptr(), dtype, bool(transpose))
@@ -352,6 +354,10 @@ def pack_weight(w, dtype, transpose=False, out=None):
             if entry is not None and entry.owner != oid:
                 del _PACKS.entries[key]        # kept for another weight that once lived at this address
                 entry = None
+            if entry is not None and out is not None and (entry.dst is None or entry.dst.data_ptr() != out.data_ptr()):
+                entry.version = -1             # the caller's buffer moved: pack into the new one
+                if torch.cuda.is_current_stream_capturing():
+                    entry = None               # (and keep nothing that lives in a graph's memory pool)
             if entry is not None and entry.version == owner._version:
                 from . import config
                 if config.debug_packs() and not torch.cuda.is_current_stream_capturing():
