@@ -136,6 +136,25 @@ typedef struct {
    * batch norm's backward need not write a masked copy (segk_bn_bwd_apply with dres = NULL). */
   const void* addend_bits;
   int addend_bits_ld;
+  /* Backward statistics of a batch norm from the launch that produces its output gradient.  When this launch is the
+   * data gradient of the convolution that consumed relu(bn(x)) (newmodeling/backbone/resnet101_2.py:33-45: conv2 after
+   * bn1 + relu, conv3 after bn2 + relu), its result `out` is dz of that batch norm, and the sums segk_bn_bwd_stats would read dz and x again for leave with the epilogue instead:
+   * bst_rows [segk_conv_bstat_rows()][2][Cout] receives per-channel partial sums of g and g * xhat, g = out where the
+   * layer's ReLU was active (bst_relu != 0) and zero elsewhere, xhat = (x - mean) * inv_std.  bst_x: the layer's input
+   * [M][bst_x_ld] (bf16, like out); bst_mean .. bst_shift: its coefficient vectors [Cout] (16-byte aligned); bst_bits:
+   * NULL (the ReLU pattern is x * scale + shift > 0) or the pattern segk_bn_apply stored, [M][bst_bits_ld] bytes.
+   * segk_bn_reduce turns the rows into the sums segk_bn_bwd_apply takes (sync_batchnorm/batchnorm.py:113-125 as
+   * autograd differentiates it).  bst_rows == NULL: nothing of this is read. */
+  double* bst_rows;
+  const void* bst_x;
+  int bst_x_ld;
+  const float* bst_mean;
+  const float* bst_inv_std;
+  const float* bst_scale;
+  const float* bst_shift;
+  const void* bst_bits;
+  int bst_bits_ld;
+  int bst_relu;
 } segk_conv_args;
 
 /* nn.Conv2d forward (modeling/aspp.py:18, modeling/decoder.py:172,178) and, with transposed packed
@@ -143,6 +162,10 @@ typedef struct {
 int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream);
 /* Number of partial rows segk_conv_fwd writes to stat_partials for this problem. */
 int segk_conv_stat_rows(const segk_conv_args* a);
+/* Number of rows segk_conv_fwd writes to bst_rows for this problem (every bst_* field but bst_rows filled in), or 0
+ * when this problem's launch cannot emit them (segk_conv_fwd then refuses a non-NULL bst_rows with
+ * SEGK_UNSUPPORTED_SHAPE and the caller runs segk_bn_bwd_stats). */
+int segk_conv_bstat_rows(const segk_conv_args* a);
 
 typedef struct {
   int N, H, W;

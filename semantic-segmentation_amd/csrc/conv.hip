@@ -68,6 +68,20 @@ struct ConvDev {
   const uint8_t* addend_bits;   // nullptr, or [M][addend_bits_ld] bytes: bit c % 8 of byte c / 8 keeps addend[m][c], a clear bit adds zero
   int addend_bits_ld;
   double* stat;
+  // Backward statistics of the batch norm whose output this launch differentiates (ring tile, bf16 output): with
+  // g = out through that layer's ReLU, partial sums of g and g * xhat per channel, one row per 80-pixel half of a tile
+  // as for `stat`.  bst_x = the layer's input [M][bst_x_ld_b bytes] (bf16); the ReLU pattern comes from bst_bits
+  // ([M][bst_bits_ld] bytes, one bit per channel) or, without them, from x * scale + shift > 0.
+  double* bst_rows;
+  const char* bst_x;
+  long long bst_x_ld_b;
+  const float* bst_mean;
+  const float* bst_inv_std;
+  const float* bst_scale;
+  const float* bst_shift;
+  const uint8_t* bst_bits;
+  int bst_bits_ld;
+  int bst_relu;
   long long m_begin;     // first pixel of this launch (a problem may be cut into a main and a tail launch)
   long long stat_row0;   // statistic partial row of this launch's first pixel tile
   int ring_tiles;        // ring tile: pixel tiles x output-channel tiles of the launch (workgroups may walk over several)
@@ -1616,7 +1630,9 @@ __device__ __forceinline__ unsigned taps_of_pixel(int y, int x, int d, int H, in
   return (y - d >= 0 ? xb : 0u) | (xb << 3) | (y + d < H ? xb << 6 : 0u);
 }
 
-template <typename TO, int STAGES, int MW, int LW, int BCO = 128>
+// BST: the variant whose epilogue can also emit a batch norm's backward statistics (ConvDev::bst_rows); a separate
+// instantiation, so that the register allocation of the plain kernel is not touched by it.
+template <typename TO, int STAGES, int MW, int LW, int BCO = 128, bool BST = false>
 // (second launch bound = wavefronts per SIMD: one workgroup per CU with three stages, two with two)
 __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) / 4) void conv_fwd_ring_kernel(const ConvDev p) {
   typedef TileCfg<BCO, RING_PX, MW / 2, 2> G;
@@ -2080,6 +2096,103 @@ __global__ __launch_bounds__(64 * (LW + MW), (STAGES >= 3 ? 1 : 2) * (LW + MW) /
       if constexpr (sizeof(TO) == 2) {
         const bool wide16 = __builtin_amdgcn_readfirstlane(((((uintptr_t)obase) & 15) == 0 && (p.out_ld & 7) == 0 &&
                                                              (!p.addend || ((((uintptr_t)p.addend) | (uintptr_t)p.addend_ld_b) & 15) == 0)) ? 1 : 0) != 0;
+        if constexpr (BST) {
+          static_assert(sizeof(TO) == 2, "the statistics epilogue stores bf16");
+          if (wide16 && __builtin_amdgcn_readfirstlane(p.bst_rows != nullptr ? 1 : 0)) {
+          const int cbase = co0 + wr * (MI * 16) + ((fg & 1) ? 16 + (fg - 1) * 4 : fg * 4);
+          // Per pair of 16-channel blocks a lane finishes eight consecutive channels (cbase + i * 16 .. + 7) of its MJ
+          // pixels.  The producing layer's input and ReLU pattern are requested for all MJ pixels before the first
+          // result is stored: behind a store the compiler may not move a load up (the buffers might overlap), and MJ
+          // loads taken one at a time are MJ memory latencies in a row.  (No addend in this variant.)
+          const bool bits_given = __builtin_amdgcn_readfirstlane(p.bst_bits != nullptr ? 1 : 0) != 0;
+          const bool recompute = __builtin_amdgcn_readfirstlane((p.bst_relu && !p.bst_bits) ? 1 : 0) != 0;
+          const long long mrow = m0 + wc * (MJ * 16) + frow;   // pixel of j = 0
+          auto finish_store = [&](int i, int j, long long m) -> u32x4 {
+            unsigned a0 = pack_bf16x2(acc[i][j][0], acc[i][j][1]), a1 = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+            unsigned b0 = pack_bf16x2(acc[i + 1][j][0], acc[i + 1][j][1]), b1 = pack_bf16x2(acc[i + 1][j][2], acc[i + 1][j][3]);
+            const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+            const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+            if (m < p.M) *reinterpret_cast<u32x4*>(obase + ((size_t)m * p.out_ld + cbase) * 2 + i * 32) = o;
+            return o;
+          };
+#pragma unroll
+          for (int i = 0; i < MI; i += 2) {
+            const int c8 = cbase + i * 16;
+            // Statistics of the producing layer's batch-norm backward from the values as they are stored: per lane the
+            // sums over its MJ pixels of g and g * xhat for its eight channels (fp32, as the stand-alone pass
+            // accumulates them), then over the 16 pixels of the DPP row in fp64; one partial row per wavefront column,
+            // as for the forward statistics.
+            u32x4 xr[MJ];
+            unsigned kb[MJ];
+#pragma unroll
+            for (int j = 0; j < MJ; ++j) {
+              const long long m = mrow + j * 16;
+              xr[j] = u32x4{0u, 0u, 0u, 0u};
+              kb[j] = 0xffu;
+              if (m < p.M) {
+                xr[j] = *reinterpret_cast<const u32x4*>(p.bst_x + (size_t)m * p.bst_x_ld_b + (size_t)c8 * 2);
+                if (bits_given) kb[j] = p.bst_bits[(size_t)m * p.bst_bits_ld + (c8 >> 3)];
+              }
+            }
+            float mu[8], is[8], sa[8], sb[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.bst_mean + c8 + h * 4);
+              const f32x4 t1 = *reinterpret_cast<const f32x4*>(p.bst_inv_std + c8 + h * 4);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) { mu[h * 4 + k] = t0[k]; is[h * 4 + k] = t1[k]; }
+            }
+            if (recompute) {   // the ReLU pattern from x * scale + shift, into kb
+              float sc[8], sh[8];
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                const f32x4 t2 = *reinterpret_cast<const f32x4*>(p.bst_scale + c8 + h * 4);
+                const f32x4 t3 = *reinterpret_cast<const f32x4*>(p.bst_shift + c8 + h * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { sc[h * 4 + k] = t2[k]; sh[h * 4 + k] = t3[k]; }
+              }
+#pragma unroll
+              for (int j = 0; j < MJ; ++j) {
+                unsigned pat = 0u;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                  const unsigned xw = xr[j][k >> 1];
+                  const float xv = __uint_as_float((k & 1) ? (xw & 0xffff0000u) : (xw << 16));
+                  pat |= (fmaf(xv, sc[k], sh[k]) > 0.f ? 1u : 0u) << k;
+                }
+                kb[j] = pat;
+              }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sa[k] = sb[k] = 0.f;
+#pragma unroll
+            for (int j = 0; j < MJ; ++j) {
+              const long long m = mrow + j * 16;
+              const u32x4 o = finish_store(i, j, m);
+              if (m < p.M) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                  const unsigned ow = o[k >> 1], xw = xr[j][k >> 1];
+                  float g = __uint_as_float((k & 1) ? (ow & 0xffff0000u) : (ow << 16));
+                  const float xv = __uint_as_float((k & 1) ? (xw & 0xffff0000u) : (xw << 16));
+                  g = ((kb[j] >> k) & 1u) ? g : 0.f;
+                  sa[k] += g;
+                  sb[k] = fmaf(g, (xv - mu[k]) * is[k], sb[k]);
+                }
+              }
+            }
+            double v[16];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[k] = (double)sa[k]; v[8 + k] = (double)sb[k]; }
+            row16_reduce_scatter<16>(v, lane);
+            const int base = row16_scatter_base<16>(lane);
+            double* brow = p.bst_rows + (size_t)((p.stat_row0 + mt) * 2 + wc) * 2 * p.Cout;
+            brow[(size_t)(base >> 3) * p.Cout + c8 + (base & 7)] = v[0];
+          }
+          continue;
+          }
+        }
         if (wide16) {
           const int cbase = co0 + wr * (MI * 16) + ((fg & 1) ? 16 + (fg - 1) * 4 : fg * 4);
 #pragma unroll
@@ -2282,7 +2395,7 @@ static int cu_count() {
 
 // The grid of a ring launch: every tile its own workgroup while they all fit on the chip at once, otherwise as many
 // workgroups as fit (a multiple of 8: one run of tiles per XCD), each walking over several tiles.
-template <typename TO, int STAGES, int MW, int LW = 4, int BCO = 128>
+template <typename TO, int STAGES, int MW, int LW = 4, int BCO = 128, bool BST = false>
 static int launch_ring(ConvDev& d, hipStream_t st, int batch, long long px_tiles) {
   constexpr int lds = STAGES * (BCO + RING_PX) * 128;
   d.n_tiles = ceil_div(d.Cout, BCO);
@@ -2299,9 +2412,9 @@ static int launch_ring(ConvDev& d, hipStream_t st, int batch, long long px_tiles
     if (grid < 8) grid = 8;
   }
   static LdsConfigured configured;  // per instantiation
-  int rc = set_lds(conv_fwd_ring_kernel<TO, STAGES, MW, LW, BCO>, lds, "conv_fwd_ring", configured);
+  int rc = set_lds(conv_fwd_ring_kernel<TO, STAGES, MW, LW, BCO, BST>, lds, "conv_fwd_ring", configured);
   if (rc != SEGK_OK) return rc;
-  conv_fwd_ring_kernel<TO, STAGES, MW, LW, BCO><<<dim3((unsigned)grid, (unsigned)batch), 64 * (LW + MW), lds, st>>>(d);
+  conv_fwd_ring_kernel<TO, STAGES, MW, LW, BCO, BST><<<dim3((unsigned)grid, (unsigned)batch), 64 * (LW + MW), lds, st>>>(d);
   return SEGK_OK;
 }
 
@@ -2852,7 +2965,41 @@ static bool fill_dev(const segk_conv_args* a, ConvDev& d) {
   d.addend_ld_b = (long long)a->addend_ld * dtype_size(a->out_dtype);
   d.addend_bits = (const uint8_t*)a->addend_bits;
   d.addend_bits_ld = a->addend_bits_ld;
+  d.bst_rows = nullptr;  // set by segk_conv_fwd once the launch is known to emit them from every tile
+  d.bst_x = (const char*)a->bst_x;
+  d.bst_x_ld_b = (long long)a->bst_x_ld * 2;
+  d.bst_mean = a->bst_mean; d.bst_inv_std = a->bst_inv_std; d.bst_scale = a->bst_scale; d.bst_shift = a->bst_shift;
+  d.bst_bits = (const uint8_t*)a->bst_bits;
+  d.bst_bits_ld = a->bst_bits_ld;
+  d.bst_relu = a->bst_relu;
   return wide;
+}
+
+// Whether a launch with this plan writes the backward-statistics rows from every tile: ring tiles whose stores take the
+// 16-byte path (bf16 output, whole tiles of channels, aligned rows, no biases, no addend), one problem per launch.
+static bool bstat_problem(const segk_conv_args* a, const TilePlan& plan, int batch) {
+  if (!a->bst_x || !a->bst_mean || !a->bst_inv_std) return false;
+  // (the 128-channel form only: the 256-channel form has no registers to spare, and the loads its epilogue would need
+  // cost it more than the stand-alone pass takes)
+  if (plan.ring != 1 || a->out_dtype != SEGK_BF16 || batch != 1 || a->bias || a->img_bias || a->addend) return false;
+  if (a->Cout % 128 != 0) return false;
+  if (!aligned16(a->out) || a->out_ld % 8 != 0) return false;
+  if (!aligned16(a->bst_x) || a->bst_x_ld % 8 != 0 || a->bst_x_ld < a->Cout) return false;
+  if (!aligned16(a->bst_mean) || !aligned16(a->bst_inv_std)) return false;
+  if (a->bst_bits) return (long long)a->bst_bits_ld * 8 >= a->Cout;
+  if (a->bst_relu) return a->bst_scale && a->bst_shift && aligned16(a->bst_scale) && aligned16(a->bst_shift);
+  return true;
+}
+
+extern "C" int segk_conv_bstat_rows(const segk_conv_args* a) {
+  if (!a || a->N <= 0 || a->H <= 0 || a->W <= 0 || a->nseg < 1 || a->nseg > SEGK_MAX_SEG || !valid_dtype(a->dtype))
+    return SEGK_INVALID_ARG;
+  if (small_rows_problem(a)) return 0;
+  ConvDev d;
+  const bool wide = fill_dev(a, d);
+  const int batch = a->batch > 1 ? a->batch : 1;
+  const TilePlan plan = plan_tiles(d, wide, batch, a->dtype == SEGK_BF16);
+  return bstat_problem(a, plan, batch) ? plan_stat_rows(d, plan) : 0;
 }
 
 extern "C" int segk_conv_stat_rows(const segk_conv_args* a) {
@@ -2891,6 +3038,12 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
                  a->addend_bits_ld, a->Cout);
   } else {
     SEGK_REQUIRE(!a->addend_bits, "conv: addend_bits without an addend");
+  }
+  if (a->bst_rows) {
+    SEGK_UNSUPPORTED(bstat_problem(a, plan, batch),
+                     "conv: backward statistics need the 128-channel ring tiles with bf16 output, whole channel tiles, 16-byte "
+                     "aligned rows and coefficient vectors, no biases, no addend (ask segk_conv_bstat_rows first)");
+    d.bst_rows = a->bst_rows;
   }
   d.stat_batch = (long long)plan_stat_rows(d, plan) * 2 * d.Cout;
   hipStream_t st = (hipStream_t)stream;
@@ -2932,7 +3085,9 @@ extern "C" int segk_conv_fwd(const segk_conv_args* a, segk_stream_t stream) {
     else if (f == 5) rc = SEGK_RING(3, 4, 4);
     else
 #endif
-    if (f == 6)
+    if (d.bst_rows)   // (bstat_problem: the 128-channel form, bf16 output)
+      rc = launch_ring<bf16_t, 3, 8, 4, 128, true>(d, st, batch, plan.main_tiles);
+    else if (f == 6)
       rc = a->out_dtype == SEGK_BF16 ? launch_ring<bf16_t, 3, 8, 4, 256>(d, st, batch, plan.main_tiles)
                                      : launch_ring<float, 3, 8, 4, 256>(d, st, batch, plan.main_tiles);
     else

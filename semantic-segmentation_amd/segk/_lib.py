@@ -27,7 +27,10 @@ class ConvArgs(ctypes.Structure):
                 ("seg", ConvSeg * MAX_SEG), ("out", c_void_p), ("out_ld", c_int), ("out_dtype", c_int),
                 ("bias", c_void_p), ("img_bias", c_void_p), ("stat_partials", c_void_p), ("batch", c_int),
                 ("w_batch", c_ll), ("out_batch", c_ll), ("dil_step", c_int), ("addend", c_void_p),
-                ("addend_ld", c_int), ("addend_bits", c_void_p), ("addend_bits_ld", c_int)]
+                ("addend_ld", c_int), ("addend_bits", c_void_p), ("addend_bits_ld", c_int),
+                ("bst_rows", c_void_p), ("bst_x", c_void_p), ("bst_x_ld", c_int), ("bst_mean", c_void_p),
+                ("bst_inv_std", c_void_p), ("bst_scale", c_void_p), ("bst_shift", c_void_p), ("bst_bits", c_void_p),
+                ("bst_bits_ld", c_int), ("bst_relu", c_int)]
 
 
 class WgradArgs(ctypes.Structure):
@@ -73,6 +76,7 @@ SIGNATURES = {
     "segk_pack_weights": [c_void_p, c_int, c_int, c_void_p],
     "segk_conv_fwd": [ctypes.POINTER(ConvArgs), c_void_p],
     "segk_conv_stat_rows": [ctypes.POINTER(ConvArgs)],
+    "segk_conv_bstat_rows": [ctypes.POINTER(ConvArgs)],
     "segk_conv_wgrad": [ctypes.POINTER(WgradArgs), c_void_p],
     "segk_wgrad_finish": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
     "segk_wgrad_finish_strided": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_ll, c_ll, c_ll, c_int, c_int,

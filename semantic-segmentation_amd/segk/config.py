@@ -8,6 +8,7 @@ import os
 _state = {"compute_dtype": torch.float32, "legacy_clamp_eps": False, "feeder_conv": "auto", "overlap_wgrad": False,
           "group_wgrad": os.environ.get("SEGK_GROUP_WGRAD", "1") != "0",
           "wgrad_second_stream": os.environ.get("SEGK_WGRAD_SECOND_STREAM", "0") == "1",
+          "fuse_bwd_stats": os.environ.get("SEGK_FUSE_BWD_STATS", "1") != "0",
           # debug switches (each costs a host synchronisation or an extra pass where it acts)
           "debug_packs": os.environ.get("SEGK_DEBUG_PACKS", "") == "1",
           "debug_labels": os.environ.get("SEGK_DEBUG_LABELS", "") == "1",
@@ -145,6 +146,29 @@ def group_wgrad_as(flag):
         yield
     finally:
         _state["group_wgrad"] = old
+
+
+def set_fuse_bwd_stats(flag):
+    """True (default; SEGK_FUSE_BWD_STATS=0 turns it off): where a feeder unit's output reaches exactly one other unit,
+    that unit's data-gradient convolution emits the backward statistics of the first unit's batch norm from its
+    epilogue (segk.functional.StatLink) and the stand-alone pass over the gradient and the pre-normalisation output is
+    skipped.  The sums are formed in another order than the stand-alone pass forms them: gradients differ in the last
+    bits between the two settings, each is reproducible run to run."""
+    _state["fuse_bwd_stats"] = bool(flag)
+
+
+def fuse_bwd_stats():
+    return _state["fuse_bwd_stats"]
+
+
+@contextlib.contextmanager
+def fuse_bwd_stats_as(flag):
+    old = _state["fuse_bwd_stats"]
+    set_fuse_bwd_stats(flag)
+    try:
+        yield
+    finally:
+        _state["fuse_bwd_stats"] = old
 
 
 # ---- debug switches ------------------------------------------------------------------------------------------

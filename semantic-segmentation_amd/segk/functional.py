@@ -319,14 +319,17 @@ def weight_grad(weight, x, dy, N, H, W, R, dil, Cout, Cin, like=None):
     return None
 
 
-def unit_backward(rec, dz, need_dw=True, dw_like=None):
+def unit_backward(rec, dz, need_dw=True, dw_like=None, partials=None):
     """dz: pixel-major gradient w.r.t. the unit's output.  Returns (dy [M, Cout rounded up to 32] with zero
     padding = gradient w.r.t. the conv output, dW, dgamma, dbeta).  dw_like: a weight whose dtype and strides dW
-    takes (default: contiguous fp32)."""
+    takes (default: contiguous fp32).  partials: the backward statistic rows of dz when the launch that produced dz
+    has emitted them already (StatLink)."""
     N, H, W = rec.geom
     M = N * H * W
     C = rec.Cout
-    partials, cnt = ops.bn_bwd_stat_partials(dz, rec.raw, rec.coef, PM, rec.relu, rec.mask, rec.mask_scale)
+    cnt = float(M)
+    if partials is None:
+        partials, cnt = ops.bn_bwd_stat_partials(dz, rec.raw, rec.coef, PM, rec.relu, rec.mask, rec.mask_scale)
     local, dgb = ops.bn_reduce(partials, cnt, want_f32=True)
     dbeta, dgamma = dgb[0], dgb[1]
     gs = _global_sums(local, rec.sync and rec.training)
@@ -343,12 +346,14 @@ def unit_backward(rec, dz, need_dw=True, dw_like=None):
     return dy, dw, dgamma, dbeta
 
 
-def dgrad(items, geom, Cin, out_dtype, img_bias=None, addend=None, addend_bits=None):
+def dgrad(items, geom, Cin, out_dtype, img_bias=None, addend=None, addend_bits=None, stat_link=None):
     """Data gradient of one or several convolutions that share their input: items = [(dy, weight, R, dil)].
     Returns a pixel-major [M, Cin rounded up to 4] tensor of out_dtype.  addend (a pixel-major view of out_dtype, or
     None): another gradient of the same input, added in the convolution's epilogue when the kernels can
     (ops.conv_addend_ok) and by a separate addition otherwise - the same bits either way.  addend_bits (uint8
-    [M, Cin/8]): only the elements of the addend whose bit is set are added."""
+    [M, Cin/8]): only the elements of the addend whose bit is set are added.  stat_link (StatLink): the result is the
+    output gradient of the batch norm that offered the link; the launch emits that layer's backward statistics when it
+    can and leaves them in the link."""
     N, H, W = geom
     segs = []
     for dy, weight, R, dil in items:
@@ -356,8 +361,14 @@ def dgrad(items, geom, Cin, out_dtype, img_bias=None, addend=None, addend_bits=N
     cpad = ops.round_up(Cin, 4)
     out = torch.empty((N * H * W, cpad), dtype=out_dtype, device=items[0][0].device)
     fused = addend is not None and img_bias is None and ops.conv_addend_ok(segs, Cin, out_dtype, addend)
+    req = None
+    if (stat_link is not None and stat_link.offered() and img_bias is None and cpad == Cin and addend is None
+            and config.fuse_bwd_stats()):
+        req = stat_link.request()
     ops.conv_fwd(segs, N, H, W, Cin, out, img_bias=img_bias, true_ck=[it[1].shape[0] for it in items],
-                 addend=addend if fused else None, addend_bits=addend_bits if fused else None)
+                 addend=addend if fused else None, addend_bits=addend_bits if fused else None, bwd_stats=req)
+    if req is not None and req.rows is not None:
+        stat_link.fulfil(req.rows, out)
     res = out[:, :Cin] if cpad != Cin else out
     if addend is not None and not fused:
         extra = addend[:, :Cin]
@@ -877,6 +888,47 @@ class GradSlot:
         return g, b
 
 
+class StatLink:
+    """Hand-over between a unit (convolution -> batch norm -> ReLU) and the ONE unit that consumes its output.  In
+    forward the producer offers what its batch norm's backward statistics need (its pre-normalisation output, the
+    coefficient rows, the ReLU pattern if stored).  In backward the consumer runs first: its data-gradient convolution
+    produces the producer's output gradient, and its epilogue emits the partial sums of g and g * xhat from the tile in
+    registers (ops.conv_fwd(bwd_stats=...)); the producer then skips the pass that would read the gradient and its
+    own pre-normalisation output again.  The rows are only used when the gradient the producer receives IS the tensor
+    that launch wrote, unchanged (same memory, same version counter): any other route - a second consumer whose
+    gradient autograd adds, a hook - falls back to the stand-alone pass."""
+    __slots__ = ("raw", "coef", "relu", "bits", "rows", "out", "version")
+
+    def __init__(self):
+        self.raw = self.coef = self.bits = self.rows = self.out = None
+        self.relu, self.version = True, -1
+
+    def offer(self, raw, coef, relu=True, bits=None):
+        self.raw, self.coef, self.relu, self.bits = raw, coef, relu, bits
+        self.rows = self.out = None
+
+    def offered(self):
+        return self.raw is not None and self.coef is not None
+
+    def request(self):
+        return ops.BwdStatRequest(self.raw, self.coef, self.relu, self.bits)
+
+    def fulfil(self, rows, out):
+        self.rows, self.out, self.version = rows, out, out._version
+
+    def rows_for(self, gv):
+        """The emitted rows when gv (the pixel-major gradient the producer received) is the tensor they were computed
+        from, else None; the link is spent either way."""
+        rows, out, version = self.rows, self.out, self.version
+        self.raw = self.coef = self.bits = self.rows = self.out = None
+        if rows is None or out is None or gv is None:
+            return None
+        if (gv.data_ptr() != out.data_ptr() or gv.shape != out.shape or gv.stride() != out.stride()
+                or gv.dtype != out.dtype or out._version != version):
+            return None
+        return rows
+
+
 # ------------------------------------------------- feeder conv + BN + ReLU ----
 class ConvBNReLUFunction(torch.autograd.Function):
     """relu(bn(conv(x))) of a feeder bottleneck block (newmodeling/backbone/resnet101_2.py:19-21 and
@@ -889,8 +941,11 @@ class ConvBNReLUFunction(torch.autograd.Function):
     in the weight's own dtype and layout."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, conv, bn, grad_slot=None):
-        """grad_slot (GradSlot or None): a second gradient of x that another function of the block leaves there."""
+    def forward(ctx, x, weight, gamma, beta, conv, bn, grad_slot=None, stats_for=None, stats_to=None):
+        """grad_slot (GradSlot or None): a second gradient of x that another function of the block leaves there.
+        stats_for (StatLink or None): the link the unit that produced x offered - x reaches this unit only (and the
+        shortcut whose gradient arrives through grad_slot); stats_to (StatLink or None): offered to this unit's only
+        consumer."""
         N, Cin, H, W = x.shape
         R, dil = conv.kernel_size[0], conv.dilation[0]
         cd = _feeder_compute_dtype(x)
@@ -907,7 +962,12 @@ class ConvBNReLUFunction(torch.autograd.Function):
         y = torch.empty((N, Cout, H, W), dtype=cd, device=x.device, memory_format=torch.channels_last)
         rec = unit_finish(xv, raw, stats, weight, R, dil, (N, H, W), spec, gamma, beta, pm_view_of(y), relu=True)
         ctx.rec, ctx.x, ctx.grad_slot = rec, x, grad_slot
-        if pm_view_of(x) is None or x.is_contiguous():   # hand an NCHW caller an NCHW tensor back
+        ctx.stats_for, ctx.stats_to = stats_for, None
+        nchw_caller = pm_view_of(x) is None or x.is_contiguous()
+        if stats_to is not None and not nchw_caller and (y.dtype == x.dtype or torch.is_autocast_enabled()):
+            stats_to.offer(raw, rec.coef, True)
+            ctx.stats_to = stats_to
+        if nchw_caller:   # hand an NCHW caller an NCHW tensor back
             y = y.contiguous()
         return y if y.dtype == x.dtype or torch.is_autocast_enabled() else y.to(x.dtype)
 
@@ -916,8 +976,10 @@ class ConvBNReLUFunction(torch.autograd.Function):
         rec, x = ctx.rec, ctx.x
         N, H, W = rec.geom
         with ops.scoped("@feeder"):
-            dy, dw, dgamma, dbeta = unit_backward(rec, to_pm(g, rec.x.dtype), need_dw=ctx.needs_input_grad[1],
-                                                  dw_like=rec.weight)
+            gv = to_pm(g, rec.x.dtype)
+            rows = ctx.stats_to.rows_for(gv) if ctx.stats_to is not None else None
+            dy, dw, dgamma, dbeta = unit_backward(rec, gv, need_dw=ctx.needs_input_grad[1], dw_like=rec.weight,
+                                                  partials=rows)
             dx = None
             other, other_bits = ctx.grad_slot.take() if ctx.grad_slot is not None else (None, None)
             if ctx.needs_input_grad[0]:
@@ -934,13 +996,14 @@ class ConvBNReLUFunction(torch.autograd.Function):
                     ov = other_bits = None
                 else:
                     late = None
-                dxp = dgrad([(dy, rec.weight, rec.R, rec.dil)], rec.geom, rec.Cin, gd, addend=ov, addend_bits=other_bits)
+                dxp = dgrad([(dy, rec.weight, rec.R, rec.dil)], rec.geom, rec.Cin, gd, addend=ov, addend_bits=other_bits,
+                            stat_link=ctx.stats_for if late is None else None)
                 dx = grad_like(x, dxp, N, H, W)
                 if late is not None:
                     dx = dx + late.to(dx.dtype)
             elif other is not None:
                 raise RuntimeError("a gradient was left for an input that needs none")
-        return dx, dw, dgamma, dbeta, None, None, None
+        return dx, dw, dgamma, dbeta, None, None, None, None, None
 
 
 class ConvBNAddReLUFunction(torch.autograd.Function):
@@ -951,9 +1014,11 @@ class ConvBNAddReLUFunction(torch.autograd.Function):
     data-gradient convolution.  Channels_last operands of one dtype."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, residual, conv, bn, grad_slot=None):
-        """grad_slot (GradSlot or None): where the residual's gradient goes instead of back through autograd."""
+    def forward(ctx, x, weight, gamma, beta, residual, conv, bn, grad_slot=None, stats_for=None, stats_to=None):
+        """grad_slot (GradSlot or None): where the residual's gradient goes instead of back through autograd.
+        stats_for / stats_to (StatLink or None): as in ConvBNReLUFunction.forward."""
         ctx.grad_slot = grad_slot
+        ctx.stats_for, ctx.stats_to = stats_for, None
         N, Cin, H, W = x.shape
         R, dil = conv.kernel_size[0], conv.dilation[0]
         cd = _feeder_compute_dtype(x)
@@ -982,6 +1047,9 @@ class ConvBNAddReLUFunction(torch.autograd.Function):
             CAPTURE.append((y, None))
         ctx.saved = (x, xv, raw, coef, bits if bits is not None else yv, weight, (N, H, W), R, dil, spec.training,
                      spec.sync)
+        if stats_to is not None and bits is not None:
+            stats_to.offer(raw, coef, True, bits)
+            ctx.stats_to = stats_to
         return y
 
     @staticmethod
@@ -992,7 +1060,10 @@ class ConvBNAddReLUFunction(torch.autograd.Function):
         gv = to_pm(g, raw.dtype)
         if act.dtype == torch.uint8:
             gv = _vector_aligned(gv)   # the bit pattern is read by the 8-channel vector kernels only
-        partials, cnt = ops.bn_bwd_stat_partials(gv, raw, coef, PM, True, act=act)
+        partials = ctx.stats_to.rows_for(gv) if ctx.stats_to is not None else None
+        cnt = float(gv.shape[0])
+        if partials is None:
+            partials, cnt = ops.bn_bwd_stat_partials(gv, raw, coef, PM, True, act=act)
         local, dgb = ops.bn_reduce(partials, cnt, want_f32=True)
         dbeta, dgamma = dgb[0], dgb[1]
         gs = _global_sums(local, sync and training)
@@ -1009,14 +1080,14 @@ class ConvBNAddReLUFunction(torch.autograd.Function):
                 dw = weight_grad(weight, xv, dy, N, H, W, R, dil, Cout, Cin, like=weight)
             dx = None
             if ctx.needs_input_grad[0]:
-                dxp = dgrad([(dy, weight, R, dil)], geom, Cin, grad_dtype_for(x))
+                dxp = dgrad([(dy, weight, R, dil)], geom, Cin, grad_dtype_for(x), stat_link=ctx.stats_for)
                 dx = grad_like(x, dxp, N, H, W)
         if lazy:
             ctx.grad_slot.put(gv, bits=act)
         elif ctx.grad_slot is not None and ctx.needs_input_grad[4]:
             ctx.grad_slot.put(dres)
             dres = None
-        return dx, dw, dgamma, dbeta, (dres if ctx.needs_input_grad[4] else None), None, None, None
+        return dx, dw, dgamma, dbeta, (dres if ctx.needs_input_grad[4] else None), None, None, None, None, None
 
 
 # ------------------------------------------------------------ plain conv ----

@@ -66,17 +66,30 @@ class Bottleneck(nn.Module):
         # batch-norm classes that can run a convolution, their own statistics and the ReLU as one unit do so
         unit = getattr(self.bn1, "forward_conv_relu", None)
         slot = None
+        # Links between units of which the second is the first one's only consumer (batch-norm classes that offer
+        # `new_stat_link`): the second unit's data-gradient convolution emits the backward statistics of the first
+        # one's batch norm.  link1: conv1's unit -> conv2's; link2: conv2's -> conv3's.
+        links = hasattr(self.bn1, "new_stat_link") and x.requires_grad
+        link1 = link2 = None
         if unit is not None and self.bn1.can_fuse_conv(self.conv1, x):
             # x feeds conv1 and (without a projection) the shortcut: the unit behind bn3 may leave the shortcut's
             # gradient in `slot`, and conv1's data-gradient convolution adds it (one gradient for x, no separate sum)
             if self.downsample is None and x.requires_grad and hasattr(self.bn1, "new_grad_slot"):
                 slot = self.bn1.new_grad_slot()
-            y = unit(self.conv1, x, slot) if slot is not None else unit(self.conv1, x)
+            if links:
+                link1 = self.bn1.new_stat_link()
+                y = unit(self.conv1, x, slot, None, link1)
+            else:
+                y = unit(self.conv1, x, slot) if slot is not None else unit(self.conv1, x)
         else:
             y = _bn_relu(self.bn1, self.relu, self.conv1(x))
         unit = getattr(self.bn2, "forward_conv_relu", None)
         if unit is not None and self.bn2.can_fuse_conv(self.conv2, y):
-            y = unit(self.conv2, y)
+            if links:
+                link2 = self.bn2.new_stat_link()
+                y = unit(self.conv2, y, None, link1, link2)
+            else:
+                y = unit(self.conv2, y)
         else:
             y = _bn_relu(self.bn2, self.relu2, self.conv2(y))
         unit = getattr(self.bn3, "forward_conv_add_relu", None)
@@ -84,6 +97,8 @@ class Bottleneck(nn.Module):
             # (x receives two gradients, from this path and from conv1: their sum does not depend on the order)
             res = x if self.downsample is None else self.downsample(x)
             if self.bn3.can_fuse_conv_residual(self.conv3, y, res):
+                if links:
+                    return unit(self.conv3, y, res, slot, link2)
                 return unit(self.conv3, y, res, slot) if slot is not None else unit(self.conv3, y, res)
             y = self.conv3(y)
         else:

@@ -89,10 +89,18 @@ class _SynchronizedBatchNorm(_BatchNorm):
             return SF.pm_view_of(input) is not None and not input.is_contiguous()
         return True
 
-    def forward_conv_relu(self, conv, input, grad_slot=None):
+    @staticmethod
+    def new_stat_link():
+        """For two units of which the second is the only consumer of the first one's output: pass the link as
+        `stats_to` to the first and as `stats_for` to the second, and the second unit's data-gradient convolution emits
+        the backward statistics of the first unit's batch norm (segk.functional.StatLink)."""
+        return SF.StatLink()
+
+    def forward_conv_relu(self, conv, input, grad_slot=None, stats_for=None, stats_to=None):
         """relu(self(conv(input))) as one unit on the implicit-GEMM kernels (statistics from the convolution's
         epilogue): a feeder bottleneck's conv2 -> bn2 -> relu, or its conv1 -> bn1 -> relu."""
-        return SF.ConvBNReLUFunction.apply(input, conv.weight, self.weight, self.bias, conv, self, grad_slot)
+        return SF.ConvBNReLUFunction.apply(input, conv.weight, self.weight, self.bias, conv, self, grad_slot, stats_for,
+                                           stats_to)
 
     def can_fuse_conv_residual(self, conv, input, residual):
         """Whether forward_conv_add_relu(conv, input, residual) applies: a 1x1 convolution from 128 or more channels
@@ -115,10 +123,11 @@ class _SynchronizedBatchNorm(_BatchNorm):
                 and SF.pm_view_of(input) is not None and not input.is_contiguous()
                 and SF.pm_view_of(residual) is not None and not residual.is_contiguous())
 
-    def forward_conv_add_relu(self, conv, input, residual, grad_slot=None):
+    def forward_conv_add_relu(self, conv, input, residual, grad_slot=None, stats_for=None, stats_to=None):
         """relu(self(conv(input)) + residual) as one unit on the implicit-GEMM kernels: a feeder bottleneck's
         conv3 -> bn3 -> += residual -> relu."""
-        return SF.ConvBNAddReLUFunction.apply(input, conv.weight, self.weight, self.bias, residual, conv, self, grad_slot)
+        return SF.ConvBNAddReLUFunction.apply(input, conv.weight, self.weight, self.bias, residual, conv, self, grad_slot,
+                                              stats_for, stats_to)
 
     def __data_parallel_replicate__(self, ctx, copy_id):
         raise RuntimeError("this SynchronizedBatchNorm runs one process per GPU (torch.distributed); "

@@ -403,14 +403,28 @@ def weight_usable_in_place(w, R, Cout):
     return w.stride(1) == 1 and w.stride(3) == Cin and w.stride(2) == R * Cin and w.stride(0) == R * R * Cin
 
 
+class BwdStatRequest:
+    """What conv_fwd(..., bwd_stats=...) needs to emit a batch norm's backward statistics from the data-gradient launch
+    that produces the layer's output gradient: raw = the layer's input [M, C] (pixel-major bf16), coef = its [4, C]
+    coefficient rows, relu = whether a ReLU follows it, bits = the stored ReLU pattern ([M, C/8] uint8) or None (the
+    pattern is raw * scale + shift > 0).  conv_fwd leaves the [rows, 2, C] float64 partial sums of g and g * xhat in
+    `rows` when the launch can emit them, None otherwise."""
+    __slots__ = ("raw", "coef", "relu", "bits", "rows")
+
+    def __init__(self, raw=None, coef=None, relu=True, bits=None):
+        self.raw, self.coef, self.relu, self.bits, self.rows = raw, coef, relu, bits, None
+
+
 def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=False, true_ck=None, batch=1,
-             dil_step=0, out_batch=0, addend=None, addend_bits=None):
+             dil_step=0, out_batch=0, addend=None, addend_bits=None, bwd_stats=None):
     """segs: list of (in_view [M, >=Ck], packed_w [taps, Cout, Ck], R, dil); instead of a packed operand a segment
     may carry the nn.Conv2d weight itself when it is channels_last [Cout, Cin, R, R] of the operand dtype with Cin a
     multiple of 32 (used in place).  Writes `out` ([M, Cout'] view, Cout' >= Cout rounded up to 4).  Returns the [rows, 2, Cout] statistic partials when want_stats.
     true_ck: un-padded contracted channel counts per segment (only used for FLOP accounting).
     addend: pixel-major view [M, >=Cout] of out's dtype: out = round(conv) + addend (see conv_addend_ok);
-    addend_bits: uint8 [M, >=Cout/8] beside it, one bit per element: a clear bit adds zero instead."""
+    addend_bits: uint8 [M, >=Cout/8] beside it, one bit per element: a clear bit adds zero instead.
+    bwd_stats (BwdStatRequest): `out` is the output gradient of the batch norm the request describes; its backward
+    statistics are written by this launch when the kernels can (request.rows is then set)."""
     M = N * H * W
     timer_ck = true_ck if true_ck is not None else [(w.shape[1] if w.dim() == 4 and batch <= 1 else w.shape[-1])
                                                     for _, w, _, _ in segs]
@@ -482,6 +496,25 @@ def conv_fwd(segs, N, H, W, Cout, out, bias=None, img_bias=None, want_stats=Fals
         a.stat_partials = stats.data_ptr()
     else:
         a.stat_partials = None
+    a.bst_rows = None
+    if bwd_stats is not None:
+        bwd_stats.rows = None
+        q = bwd_stats
+        if (addend is None and q.raw is not None and q.raw.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and q.raw.dim() == 2
+                and q.raw.shape[0] == M and q.raw.shape[1] == Cout and q.raw.stride(1) == 1 and q.coef.shape == (4, Cout)
+                and q.coef.dtype == torch.float32 and q.coef.is_contiguous()
+                and (q.bits is None or (q.bits.dtype == torch.uint8 and q.bits.dim() == 2 and q.bits.is_contiguous()
+                                        and q.bits.shape[0] == M))):
+            _dev(q.raw, q.coef, q.bits)
+            r = _row_ptrs(q.coef)
+            a.bst_x, a.bst_x_ld = q.raw.data_ptr(), q.raw.stride(0)
+            a.bst_mean, a.bst_inv_std, a.bst_scale, a.bst_shift = r[0].value, r[1].value, r[2].value, r[3].value
+            a.bst_bits, a.bst_bits_ld = (q.bits.data_ptr(), q.bits.shape[1]) if q.bits is not None else (None, 0)
+            a.bst_relu = 1 if q.relu else 0
+            rows = call("segk_conv_bstat_rows", ctypes.byref(a))
+            if rows > 0:
+                q.rows = torch.empty((rows, 2, Cout), dtype=torch.float64, device=out.device)
+                a.bst_rows = q.rows.data_ptr()
     t0 = TIMER.start() if TIMER is not None else None
     call("segk_conv_fwd", ctypes.byref(a), _stream())
     if t0 is not None:

@@ -267,6 +267,60 @@ def test_bottleneck_shortcut_gradient_added_in_the_data_gradient(planes, hw):
     assert float(with_slot[0].float().abs().max()) > 0
 
 
+def test_bottleneck_backward_statistics_from_the_data_gradient():
+    """Three identical bottlenecks on a 33 x 33 map (newmodeling/backbone/resnet101_2.py:31-51): the data-gradient
+    convolution of conv2 emits the backward statistics of bn1 and that of conv3 those of bn2; the stand-alone
+    statistics pass then runs for bn3 only.  Gradients equal those of the stand-alone passes up to the summation order,
+    and are the same bits run to run."""
+    from unittest import mock
+
+    from segk import config, ops
+    from segk.modeling.backbone.resnet import Bottleneck
+    from segk.modeling.sync_batchnorm import SynchronizedBatchNorm2d
+    dev = "cuda"
+    torch.manual_seed(5)
+    planes = 256
+    net = nn.Sequential(*[Bottleneck(planes * 4, planes, 1, 1, None, SynchronizedBatchNorm2d) for _ in range(3)])
+    net = net.to(dev).to(memory_format=torch.channels_last)
+    for m in net.modules():
+        if isinstance(m, nn.Conv2d):
+            m.weight.data = m.weight.data.to(torch.bfloat16)
+    x0 = torch.randn(4, planes * 4, 33, 33, device=dev).relu().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn_like(x0)
+    calls = []
+    real = ops.bn_bwd_stat_partials
+
+    def counting(dz, x, *a, **k):
+        calls.append(tuple(x.shape))
+        return real(dz, x, *a, **k)
+
+    def rel(a, b):
+        return float((a.float() - b.float()).abs().max() / b.float().abs().max())
+
+    def run(fuse):
+        net.zero_grad(set_to_none=True)
+        del calls[:]
+        x = x0.clone().requires_grad_(True)
+        with config.fuse_bwd_stats_as(fuse), mock.patch.object(ops, "bn_bwd_stat_partials", counting):
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                y = net(x)
+            y.backward(gy)
+        torch.cuda.synchronize()
+        return x.grad.clone(), [p.grad.clone() for p in net.parameters()], list(calls)
+
+    gx0, alone, n_alone = run(False)
+    assert len(n_alone) == 9, n_alone
+    gx1, fused, n_fused = run(True)
+    assert n_fused == [(4 * 33 * 33, planes * 4)] * 3, n_fused     # bn3 of the three blocks
+    assert rel(gx1, gx0) < 2e-2
+    for p, a, b in zip(net.parameters(), alone, fused):
+        assert rel(b, a) < 2e-2, (tuple(p.shape), rel(b, a))
+    gx2, again, _ = run(True)
+    assert torch.equal(gx1, gx2)
+    for a, b in zip(fused, again):
+        assert torch.equal(a, b)
+
+
 def test_repeated_bottlenecks_weight_gradients_in_groups():
     """Five identical bottlenecks on a 33 x 33 map (what ResNet-101's layer 3 repeats 22 times,
     newmodeling/backbone/resnet101_2.py:100-122): with overlap_wgrad the weight gradients of one shape are collected

@@ -189,6 +189,92 @@ def test_conv_addend_and_bit_pattern(ops, case, out_dtype, shift):
         ops.conv_fwd([(xv, wp, R, dil)], N, H, W, Cout, out, addend_bits=bits)
 
 
+BSTAT_CASES = [(2, 17, 15, 128, 256, 3, 2), (1, 33, 33, 256, 128, 1, 1), (16, 33, 33, 1024, 256, 1, 1),
+               (4, 33, 33, 64, 512, 1, 1)]
+
+
+@pytest.mark.parametrize("case", BSTAT_CASES)
+@pytest.mark.parametrize("mode", ["recompute", "bits", "linear"])
+def test_conv_emits_bn_backward_statistics(ops, case, mode):
+    """segk_conv_args.bst_*: a data-gradient launch whose result is the output gradient of a batch norm leaves that
+    layer's backward statistics (partial sums of g and g * xhat, g = the stored result through the layer's ReLU) from
+    its epilogue.  Against segk_bn_bwd_stats on the tensor the same launch wrote, and against float64 PyTorch; the
+    pixel counts include tiles with a ragged end."""
+    from segk._lib import PM
+    N, H, W, Cin, Cout, R, dil = case
+    M = N * H * W
+    x, w = _conv_inputs(case)
+    xv = to_pm(x, torch.bfloat16)[0]
+    wp = ops.pack_weight(w, torch.bfloat16)
+    raw = T(gen.normal(15, "bst_raw%s" % (case,), (M, Cout)), torch.bfloat16)
+    coef = torch.stack([T(gen.normal(15, "bst_mu%d" % Cout, (Cout,), std=0.3)),
+                        T(np.abs(gen.normal(15, "bst_is%d" % Cout, (Cout,))) + 0.5),
+                        T(gen.normal(15, "bst_sc%d" % Cout, (Cout,))),
+                        T(gen.normal(15, "bst_sh%d" % Cout, (Cout,), std=0.3))]).contiguous()
+    bits = None
+    if mode == "bits":
+        bits = torch.from_numpy(gen.integers(15, "bst_b%s" % (case,), (M, Cout // 8), 0, 256).astype(np.uint8)).to(DEV)
+    relu = mode != "linear"
+    plain = torch.empty((M, Cout), dtype=torch.bfloat16, device=DEV)
+    ops.conv_fwd([(xv, wp, R, dil)], N, H, W, Cout, plain)
+    out = torch.full((M, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+    req = ops.BwdStatRequest(raw, coef, relu, bits)
+    ops.conv_fwd([(xv, wp, R, dil)], N, H, W, Cout, out, bwd_stats=req)
+    assert req.rows is not None and req.rows.shape[1:] == (2, Cout)
+    assert torch.equal(out, plain)                       # the output itself is untouched by the request
+    got = ops.bn_reduce(req.rows, float(M))
+    part, cnt = ops.bn_bwd_stat_partials(out, raw, coef, PM, relu, act=bits)
+    ref = ops.bn_reduce(part, cnt)
+    # float64 PyTorch on the same stored values
+    g = out.double()
+    xf = raw.float()
+    if mode == "bits":
+        g = g * ops.unpack_bits(bits, Cout).double()
+    elif mode == "recompute":
+        g = g * (torch.addcmul(coef[3], xf, coef[2]) > 0).double()
+    xhat = ((xf - coef[0]) * coef[1]).double()
+    want = torch.cat([g.sum(0), (g * xhat).sum(0), torch.tensor([float(M)], dtype=torch.float64, device=DEV)])
+    scale = torch.cat([g.abs().sum(0), (g * xhat).abs().sum(0), torch.ones(1, dtype=torch.float64, device=DEV)])
+    for name, other in (("segk_bn_bwd_stats", ref), ("float64", want)):
+        err = float(((got - other).abs() / (scale + 1e-30)).max())
+        assert err < 4e-6, (name, err)
+    assert float(got[2 * Cout]) == float(M)
+
+
+def test_conv_backward_statistics_declined_where_the_tiles_cannot(ops):
+    """fp32 output, a channel count that leaves part of a tile empty, a misaligned pre-normalisation tensor, an addend,
+    or a problem that takes the 256-channel tiles (they have no registers to spare for it): the request comes back without
+    rows (the caller runs the stand-alone pass) and the convolution itself is unchanged."""
+    R, dil = 1, 1
+    for N, H, W, Cin, Cout, out_dtype, shift in ((1, 9, 9, 64, 128, torch.float32, 0), (1, 9, 9, 64, 192, torch.bfloat16, 0),
+                                                 (1, 9, 9, 64, 128, torch.bfloat16, 4),
+                                                 (16, 33, 33, 64, 1024, torch.bfloat16, 0)):
+        M = N * H * W
+        x = T(gen.normal(15, "bsd_x%d" % N, (N, Cin, H, W)))
+        xv = to_pm(x, torch.bfloat16)[0]
+        w = T(gen.normal(15, "bsd_w%d" % Cout, (Cout, Cin, 1, 1), std=0.05))
+        wp = ops.pack_weight(w, torch.bfloat16)
+        raw_buf = torch.zeros((M, Cout + 8), dtype=torch.bfloat16, device=DEV)
+        raw = raw_buf[:, shift:shift + Cout]
+        coef = torch.ones((4, Cout), dtype=torch.float32, device=DEV)
+        out = torch.empty((M, Cout), dtype=out_dtype, device=DEV)
+        plain = torch.empty_like(out)
+        ops.conv_fwd([(xv, wp, R, dil)], N, H, W, Cout, plain)
+        req = ops.BwdStatRequest(raw, coef, True, None)
+        ops.conv_fwd([(xv, wp, R, dil)], N, H, W, Cout, out, bwd_stats=req)
+        assert req.rows is None
+        assert torch.equal(out, plain)
+    # ... or beside an addend
+    Cout = 128
+    raw = torch.zeros((M, Cout), dtype=torch.bfloat16, device=DEV)
+    req = ops.BwdStatRequest(raw, torch.ones((4, Cout), dtype=torch.float32, device=DEV), True, None)
+    w = T(gen.normal(15, "bsd_wa", (Cout, Cin, 1, 1), std=0.05))
+    out = torch.empty((M, Cout), dtype=torch.bfloat16, device=DEV)
+    ops.conv_fwd([(xv, ops.pack_weight(w, torch.bfloat16), R, dil)], N, H, W, Cout, out, addend=torch.ones_like(out),
+                 bwd_stats=req)
+    assert req.rows is None
+
+
 def test_conv_addend_refused_off_the_ring_tile(ops):
     N, H, W, Cin, Cout = 1, 9, 9, 64, 64      # 64 output channels: not a multiple of 128
     x = T(gen.normal(13, "adr_x", (N, Cin, H, W)))

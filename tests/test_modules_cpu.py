@@ -91,3 +91,38 @@ def test_gradient_buckets_partition_parameters_in_reverse_order():
     assert [id(p) for p in order] == [id(p) for p in reversed(ps)]
     assert all(sum(p.numel() for p in bucket) <= 262144 or len(bucket) == 1 for bucket in b.buckets)
     assert all(id(p) != id(frozen) for p in order)
+
+
+def test_stat_link_only_hands_rows_to_the_tensor_they_were_computed_from():
+    """segk.functional.StatLink: backward statistics emitted by a data-gradient launch are used only when the gradient
+    the producing unit receives is that launch's output, unchanged - the same memory, shape and strides and no
+    in-place write since (a second consumer whose gradient autograd adds in place moves the version counter; one it
+    adds out of place gives another tensor).  The link is spent by the first question either way."""
+    from segk.functional import StatLink
+    raw, coef, rows = torch.zeros(6, 8), torch.zeros(4, 8), torch.zeros(2, 2, 8, dtype=torch.float64)
+
+    def fulfilled():
+        link, out = StatLink(), torch.ones(6, 8)
+        assert not link.offered()
+        link.offer(raw, coef, True)
+        assert link.offered()
+        req = link.request()
+        assert req.raw is raw and req.coef is coef and req.relu and req.bits is None and req.rows is None
+        link.fulfil(rows, out)
+        return link, out
+
+    link, out = fulfilled()
+    assert link.rows_for(out.view(6, 8)) is rows          # a view of the same memory is the same gradient
+    assert link.rows_for(out) is None and not link.offered()   # spent
+    link, out = fulfilled()
+    assert link.rows_for(out + 0) is None                  # another tensor
+    link, out = fulfilled()
+    out.add_(1.0)                                          # written in place after the launch
+    assert link.rows_for(out) is None
+    link, out = fulfilled()
+    assert link.rows_for(out[:3]) is None                  # another shape
+    link, out = fulfilled()
+    assert link.rows_for(out.t().contiguous().t()) is None  # other strides (and memory)
+    link = StatLink()
+    link.offer(raw, coef, True)
+    assert link.rows_for(torch.ones(6, 8)) is None         # offered, never fulfilled

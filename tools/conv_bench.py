@@ -45,6 +45,9 @@ def main():
            # the feeder's stride-1 bottleneck 3x3s (ResNet layers 3 and 4 at output stride 16)
            ("feeder l3 3x3", 33, 256, 256, 256, 3, 1), ("feeder l4 3x3 d2", 33, 512, 512, 512, 3, 2),
            ("feeder l4 3x3 d4", 33, 512, 512, 512, 3, 4),
+           # ... and their 1x1 neighbours: short K loops onto many channels, long ones onto few
+           ("feeder l3 c3 1x1", 33, 256, 256, 1024, 1, 1), ("feeder l3 c1 1x1", 33, 1024, 1024, 256, 1, 1),
+           ("feeder l4 c3 1x1", 33, 512, 512, 2048, 1, 1), ("feeder l4 c1 1x1", 33, 2048, 2048, 512, 1, 1),
            # same map and output width, growing K: the slope is the cost of a K step, the intercept the fixed part
            ("probe k 3x3 c64", 33, 64, 64, 256, 3, 1), ("probe k 3x3 c128", 33, 128, 128, 256, 3, 1),
            ("probe k 3x3 c512", 33, 512, 512, 256, 3, 1), ("probe k 3x3 c1024", 33, 1024, 1024, 256, 3, 1),
