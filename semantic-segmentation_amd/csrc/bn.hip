@@ -328,8 +328,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_pm_kernel(
     long long M, int C, const float* __restrict__ mean, const float* __restrict__ inv_std,
     const float* __restrict__ scale, const float* __restrict__ shift, int relu, const uint8_t* __restrict__ mask,
     float mask_scale, const double* __restrict__ gsums, int eval, const TG* __restrict__ act, int act_ld,
-    TG* __restrict__ dres, int dres_ld) {
-  const PmThread t = pm_thread<VEC>(C, M);
+    TG* __restrict__ dres, int dres_ld, int slab) {
+  const PmThread t = pm_thread<VEC>(C, M, slab);
   // the slab's per-channel coefficients go through LDS: one coalesced load per workgroup instead of 6 x VEC
   // scattered loads (two of them fp64) per thread
   extern __shared__ float cf[];  // [6][Cs]: scale, shift, mean, inv_std, sum_g / count, sum_g_xhat / count
@@ -658,17 +658,32 @@ static int pm_vec(int C, std::initializer_list<int> lds, std::initializer_list<s
   return 1;
 }
 
-// grid of the pixel-major elementwise kernels: about four workgroups per CU, and at least `min_rows` pixels per
-// thread so that the per-thread load of the channel coefficients is amortised
-static dim3 pm_apply_grid(long long M, int C, int vec, int min_rows = 4) {
-  const int slab = BN_THREADS * vec;
+// Grid of the pixel-major elementwise kernels: about `wgs` workgroups over pixel ranges x channel slabs, at least
+// `min_rows` pixels per thread.  Measured with operands that are not in the memory-side cache (tools/bn_apply_sweep.sh,
+// 16 x 33 x 33 x 1024 bf16): the forward pass, whose threads load their own two coefficient vectors, is fastest with
+// many short workgroups (4096, two pixels per thread: 17.5 -> 15.2 us); the backward pass stages six coefficient
+// vectors of its slab through LDS and wants that amortised - slabs of 128 channels (3 KB of coefficients instead of
+// 24 KB for a 1024-channel row) and about 1024 workgroups: 30.9 -> 26.4 us with the ReLU bits, 33.5 -> 25.4 without.
+static dim3 pm_apply_grid(long long M, int C, int vec, int wgs, int min_rows, int slab = 0) {
+  if (slab <= 0) slab = BN_THREADS * vec;
   const int cg = (C < slab ? C : slab) / vec;
   const int rpb = BN_THREADS / cg;
-  long long rpt = (M + (long long)rpb * 2048 - 1) / ((long long)rpb * 2048);
+  const int slabs = ceil_div(C, slab);
+  const long long want = wgs / slabs > 0 ? wgs / slabs : 1;
+  long long rpt = (M + (long long)rpb * want - 1) / ((long long)rpb * want);
   if (rpt < min_rows) rpt = min_rows;
   long long gx = (M + rpb * rpt - 1) / (rpb * rpt);
   if (gx < 1) gx = 1;
-  return dim3((unsigned)gx, (unsigned)ceil_div(C, slab));
+  return dim3((unsigned)gx, (unsigned)slabs);
+}
+
+static int env_int(const char* name, int fallback) {
+#ifdef SEGK_EXPERIMENTS
+  const char* e = getenv(name);
+  if (e && atoi(e) > 0) return atoi(e);
+#endif
+  (void)name;
+  return fallback;
 }
 
 #define SEGK_DISPATCH_VEC(vec, V, ...)             \
@@ -792,7 +807,8 @@ extern "C" int segk_bn_apply(const void* x, int x_dtype, int x_ld, void* y, int 
     SEGK_UNSUPPORTED(!relu_bits || vec == 8,
                      "bn_apply: the ReLU bit pattern needs C and the leading dimensions to be multiples of 8 and "
                      "16-byte aligned operands");
-    const dim3 grid = pm_apply_grid(M, C, vec);
+    static const int wgs = env_int("SEGK_BN_APPLY_WGS", 4096), min_rows = env_int("SEGK_BN_APPLY_MINROWS", 2);
+    const dim3 grid = pm_apply_grid(M, C, vec, wgs, min_rows);
 #define LAUNCH_APPLY(TX, TY)                                                                                       \
   SEGK_DISPATCH_VEC(vec, V, {                                                                                      \
     if (res)                                                                                                       \
@@ -905,22 +921,25 @@ extern "C" int segk_bn_bwd_apply(const void* dz, int dz_dtype, int dz_ld, const 
     if (act && !act_bits) vec = std::min(vec, pm_vec(C, {act_ld}, {{act, dz_dtype}}, nullptr));
     if (dres) vec = std::min(vec, pm_vec(C, {dres_ld}, {{dres, dz_dtype}}, nullptr));
     SEGK_UNSUPPORTED(!act_bits || vec == 8, "bn_bwd_apply: the ReLU bit pattern needs 8-channel vector access");
-    const dim3 grid = pm_apply_grid(M, C, vec);
-    const size_t lds = (size_t)6 * (C < BN_THREADS * vec ? C : BN_THREADS * vec) * sizeof(float);
+    static const int e_slab = env_int("SEGK_BN_BAPPLY_SLAB", 128), wgs = env_int("SEGK_BN_BAPPLY_WGS", 1024),
+                     min_rows = env_int("SEGK_BN_BAPPLY_MINROWS", 4);
+    const int slab = (vec == 8 && C % e_slab == 0 && e_slab % 8 == 0 && e_slab <= BN_THREADS * vec) ? e_slab : BN_THREADS * vec;
+    const dim3 grid = pm_apply_grid(M, C, vec, wgs, min_rows, slab);
+    const size_t lds = (size_t)6 * (C < slab ? C : slab) * sizeof(float);
 #define LAUNCH_BA(TG, TX)                                                                                            \
   SEGK_DISPATCH_VEC(vec, V, {                                                                                        \
     if (act && act_bits)                                                                                             \
       bn_bwd_apply_pm_kernel<TG, TX, V, 2><<<grid, BN_THREADS, lds, st>>>(                                           \
           (const TG*)dz, dz_ld, (const TX*)x, x_ld, (TG*)dx, dx_ld, M, C, mean, inv_std, scale, shift, relu, mask,   \
-          mask_scale, gsums, eval, (const TG*)act, act_ld, (TG*)dres, dres_ld);                                      \
+          mask_scale, gsums, eval, (const TG*)act, act_ld, (TG*)dres, dres_ld, slab);                                \
     else if (act)                                                                                                    \
       bn_bwd_apply_pm_kernel<TG, TX, V, 1><<<grid, BN_THREADS, lds, st>>>(                                           \
           (const TG*)dz, dz_ld, (const TX*)x, x_ld, (TG*)dx, dx_ld, M, C, mean, inv_std, scale, shift, relu, mask,   \
-          mask_scale, gsums, eval, (const TG*)act, act_ld, (TG*)dres, dres_ld);                                      \
+          mask_scale, gsums, eval, (const TG*)act, act_ld, (TG*)dres, dres_ld, slab);                                \
     else                                                                                                             \
       bn_bwd_apply_pm_kernel<TG, TX, V, 0><<<grid, BN_THREADS, lds, st>>>(                                           \
           (const TG*)dz, dz_ld, (const TX*)x, x_ld, (TG*)dx, dx_ld, M, C, mean, inv_std, scale, shift, relu, mask,   \
-          mask_scale, gsums, eval, nullptr, 0, nullptr, 0);                                                          \
+          mask_scale, gsums, eval, nullptr, 0, nullptr, 0, slab);                                                    \
   })
     if (dz_dtype == SEGK_BF16 && x_dtype == SEGK_BF16) { LAUNCH_BA(bf16_t, bf16_t); }
     else if (dz_dtype == SEGK_BF16) { LAUNCH_BA(bf16_t, float); }
