@@ -870,10 +870,11 @@ class GradSlot:
     conv1 and the shortcut: the function that produces the shortcut's gradient (it runs first in backward) leaves it
     here instead of returning it to autograd, and conv1's function adds it inside its data-gradient convolution, so
     x receives ONE gradient and autograd's separate addition of two 36 - 136 MB tensors per block disappears."""
-    __slots__ = ("grad", "bits")
+    __slots__ = ("grad", "bits", "taken")
 
     def __init__(self):
         self.grad = self.bits = None
+        self.taken = False
 
     def put(self, g, bits=None):
         """g: the gradient (an NCHW-shaped channels_last tensor or its pixel-major view).  bits (uint8 [M, C/8], the
@@ -885,7 +886,33 @@ class GradSlot:
         """-> (gradient or None, bit pattern or None)"""
         g, b = self.grad, self.bits
         self.grad = self.bits = None
+        self.taken = True
         return g, b
+
+
+class GradToSlotFunction(torch.autograd.Function):
+    """Identity in forward.  In backward the gradient goes into a GradSlot instead of back to autograd: for a block
+    whose input x feeds conv1's unit and a projection shortcut (newmodeling/backbone/resnet101_2.py:46-47,
+    `residual = self.downsample(x)`), the shortcut's backward runs first (its nodes were recorded after conv1's and
+    conv2's), and conv1's data-gradient convolution adds what it finds in the slot - x receives one gradient instead
+    of two that autograd adds in a pass of its own.  Should the consumer already have run (another execution order, a
+    second backward pass over a kept graph), the gradient is returned to autograd as usual."""
+
+    @staticmethod
+    def forward(ctx, x, slot):
+        ctx.slot = slot
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.slot.taken:
+            return g, None
+        ctx.slot.put(g)
+        return None, None
+
+
+def grad_to_slot(x, slot):
+    return GradToSlotFunction.apply(x, slot)
 
 
 class StatLink:

@@ -74,7 +74,9 @@ class Bottleneck(nn.Module):
         if unit is not None and self.bn1.can_fuse_conv(self.conv1, x):
             # x feeds conv1 and (without a projection) the shortcut: the unit behind bn3 may leave the shortcut's
             # gradient in `slot`, and conv1's data-gradient convolution adds it (one gradient for x, no separate sum)
-            if self.downsample is None and x.requires_grad and hasattr(self.bn1, "new_grad_slot"):
+            # (with a projection it is the projection's input gradient that goes through the slot)
+            if x.requires_grad and hasattr(self.bn1, "new_grad_slot") and (
+                    self.downsample is None or hasattr(self.bn1, "gradient_to_slot")):
                 slot = self.bn1.new_grad_slot()
             if links:
                 link1 = self.bn1.new_stat_link()
@@ -93,13 +95,19 @@ class Bottleneck(nn.Module):
         else:
             y = _bn_relu(self.bn2, self.relu2, self.conv2(y))
         unit = getattr(self.bn3, "forward_conv_add_relu", None)
+        # the slot takes the gradient of the shortcut's INPUT: the residual's own gradient without a projection, the
+        # projection's input gradient with one (the unit behind bn3 then returns the residual's gradient to autograd)
+        res_slot = slot if self.downsample is None else None
         if unit is not None:
             # (x receives two gradients, from this path and from conv1: their sum does not depend on the order)
-            res = x if self.downsample is None else self.downsample(x)
+            if self.downsample is None:
+                res = x
+            else:
+                res = self.downsample(self.bn1.gradient_to_slot(x, slot) if slot is not None else x)
             if self.bn3.can_fuse_conv_residual(self.conv3, y, res):
                 if links:
-                    return unit(self.conv3, y, res, slot, link2)
-                return unit(self.conv3, y, res, slot) if slot is not None else unit(self.conv3, y, res)
+                    return unit(self.conv3, y, res, res_slot, link2)
+                return unit(self.conv3, y, res, res_slot) if res_slot is not None else unit(self.conv3, y, res)
             y = self.conv3(y)
         else:
             y = self.conv3(y)
@@ -108,7 +116,7 @@ class Bottleneck(nn.Module):
             res = x if self.downsample is None else self.downsample(x)
         fused = getattr(self.bn3, "forward_add_relu", None)
         if fused is not None and self.bn3.can_fuse_residual(y, res):
-            return fused(y, res, slot) if slot is not None else fused(y, res)
+            return fused(y, res, res_slot) if res_slot is not None else fused(y, res)
         y = self.bn3(y)
         y += res
         return self.relu(y)

@@ -90,6 +90,12 @@ class _SynchronizedBatchNorm(_BatchNorm):
         return True
 
     @staticmethod
+    def gradient_to_slot(x, slot):
+        """x for a branch whose gradient is to arrive through `slot` (segk.functional.GradToSlotFunction): the
+        projection shortcut of a block whose conv1 unit holds the same slot."""
+        return SF.grad_to_slot(x, slot)
+
+    @staticmethod
     def new_stat_link():
         """For two units of which the second is the only consumer of the first one's output: pass the link as
         `stats_to` to the first and as `stats_for` to the second, and the second unit's data-gradient convolution emits

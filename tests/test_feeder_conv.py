@@ -225,30 +225,41 @@ def test_unit_1x1_residual_backward_takes_unaligned_gradients():
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("planes,hw", [(256, 9), (64, 17)])
-def test_bottleneck_shortcut_gradient_added_in_the_data_gradient(planes, hw):
-    """An identity bottleneck (newmodeling/backbone/resnet101_2.py:31-51): its input feeds conv1 and the shortcut.  With
+@pytest.mark.parametrize("planes,hw,proj", [(256, 9, False), (64, 17, False), (256, 9, True), (128, 11, True)])
+def test_bottleneck_shortcut_gradient_added_in_the_data_gradient(planes, hw, proj):
+    """A bottleneck (newmodeling/backbone/resnet101_2.py:31-51): its input feeds conv1 and the shortcut.  With
     the gradient slot the shortcut's gradient is added in the epilogue of conv1's data-gradient convolution; without
     it autograd adds the two tensors.  Same bits in the input gradient and in every parameter gradient.  (256 planes:
     all three units on the HIP kernels; 64 planes, ResNet layer 1: conv1 on them, the shortcut's gradient comes out of
-    the stand-alone batch norm with residual.)"""
+    the stand-alone batch norm with residual.  proj: the first block of a stage, whose shortcut is a 1 x 1 convolution
+    with batch norm - the projection's input gradient goes through the slot.)"""
+    from segk import functional as SF
     from segk.modeling.backbone.resnet import Bottleneck
     from segk.modeling.sync_batchnorm import SynchronizedBatchNorm2d
     dev = "cuda"
     torch.manual_seed(planes)
-    blk = Bottleneck(planes * 4, planes, 1, 1, None, SynchronizedBatchNorm2d).to(dev).to(memory_format=torch.channels_last)
+    inplanes = planes * 2 if proj else planes * 4
+    down = None
+    if proj:
+        down = nn.Sequential(nn.Conv2d(inplanes, planes * 4, kernel_size=1, bias=False), SynchronizedBatchNorm2d(planes * 4))
+    blk = Bottleneck(inplanes, planes, 1, 1, down, SynchronizedBatchNorm2d).to(dev).to(memory_format=torch.channels_last)
     for m in blk.modules():
         if isinstance(m, nn.Conv2d):
             m.weight.data = m.weight.data.to(torch.bfloat16)
-    x0 = torch.randn(2, planes * 4, hw, hw + 2, device=dev).relu().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    gy = torch.randn_like(x0)
-    seen = []
+    x0 = torch.randn(2, inplanes, hw, hw + 2, device=dev).relu().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(2, planes * 4, hw, hw + 2, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    puts = []
+    real_put = SF.GradSlot.put
+
+    def counting_put(self, g, bits=None):
+        puts.append(tuple(g.shape))
+        return real_put(self, g, bits)
 
     def run(use_slot):
         import contextlib
         from unittest import mock
         off = mock.patch.object(SynchronizedBatchNorm2d, "new_grad_slot", staticmethod(lambda: None))
-        with (contextlib.nullcontext() if use_slot else off):
+        with (contextlib.nullcontext() if use_slot else off), mock.patch.object(SF.GradSlot, "put", counting_put):
             blk.zero_grad(set_to_none=True)
             x = x0.clone().requires_grad_(True)
             with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
@@ -265,6 +276,22 @@ def test_bottleneck_shortcut_gradient_added_in_the_data_gradient(planes, hw):
     for a, b in zip(with_slot, without):
         assert torch.equal(a, b)
     assert float(with_slot[0].float().abs().max()) > 0
+    assert len(puts) == 1, puts       # one gradient went through the slot, in the run that had one
+
+
+def test_gradient_slot_returns_to_autograd_when_its_consumer_has_run():
+    """GradToSlotFunction: should the consumer of the slot already have taken from it when the branch's gradient
+    arrives (another execution order, a second pass over a kept graph), the gradient goes back to autograd."""
+    from segk import functional as SF
+    x = torch.ones(3, device="cuda", requires_grad=True)
+    slot = SF.GradSlot()
+    y = SF.grad_to_slot(x, slot) * 2.0
+    y.sum().backward(retain_graph=True)
+    assert x.grad is None or float(x.grad.abs().sum()) == 0.0     # the gradient waits in the slot
+    g, bits = slot.take()
+    assert bits is None and torch.equal(g, torch.full((3,), 2.0, device="cuda"))
+    y.sum().backward()
+    assert torch.equal(x.grad, torch.full((3,), 2.0, device="cuda"))   # the slot is spent: autograd gets it
 
 
 def test_bottleneck_backward_statistics_from_the_data_gradient():

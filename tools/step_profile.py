@@ -5,9 +5,11 @@ The process-wide --stats table also contains warm-up and MIOpen's one-time algor
 script cuts the trace between the last two launches of a once-per-step kernel (ce_fwd_kernel) and
 prints per-kernel totals for that interval: backward of step k-1 + optimizer + forward of step k.
 
-usage: tools/step_profile.py <kernel_trace.csv> [--top N] [--hist]
+usage: tools/step_profile.py <kernel_trace.csv> [--top N] [--hist] [--others]
 --hist: for the convolution kernels, calls and time per duration class (which launches carry the time: the many
 short ones of the 33 x 33 stages or the few long ones of the head).
+--others: every kernel that is not this library's (vendor convolutions of the feeder, PyTorch glue), in launch order
+with its grid, so that a launch can be matched to the layer it belongs to.
 """
 import collections
 import csv
@@ -45,6 +47,14 @@ def main():
     print("\nsegk kernels only:")
     for k, v in sorted(((k, v) for k, v in agg.items() if "segk::" in k), key=lambda kv: -kv[1][0]):
         print("%10.3f %6d %10.1f  %s" % (v[0] / 1e6, v[1], v[0] / v[1] / 1e3, k[:130]))
+    if "--others" in sys.argv:
+        print("\nkernels of other libraries, in launch order: start (ms into the step), duration (us), grid, name")
+        for r in seg:
+            if "segk::" in r["Kernel_Name"]:
+                continue
+            s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            grid = "x".join(r.get(k, "?") for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))
+            print("%8.3f %8.1f  %-18s %s" % ((s - t0) / 1e6, (e - s) / 1e3, grid, r["Kernel_Name"][:100]))
     if "--hist" in sys.argv:
         edges = [0, 10, 15, 20, 30, 45, 70, 110, 200, 400, 10 ** 9]
         print("\nconvolution kernels by duration class (us): calls / total ms")
