@@ -9,6 +9,7 @@ _state = {"compute_dtype": torch.float32, "legacy_clamp_eps": False, "feeder_con
           "group_wgrad": os.environ.get("SEGK_GROUP_WGRAD", "1") != "0",
           "wgrad_second_stream": os.environ.get("SEGK_WGRAD_SECOND_STREAM", "0") == "1",
           "fuse_bwd_stats": os.environ.get("SEGK_FUSE_BWD_STATS", "1") != "0",
+          "head_raw_fp32": os.environ.get("SEGK_HEAD_RAW_FP32", "0") == "1",
           # debug switches (each costs a host synchronisation or an extra pass where it acts)
           "debug_packs": os.environ.get("SEGK_DEBUG_PACKS", "") == "1",
           "debug_labels": os.environ.get("SEGK_DEBUG_LABELS", "") == "1",
@@ -169,6 +170,28 @@ def fuse_bwd_stats_as(flag):
         yield
     finally:
         _state["fuse_bwd_stats"] = old
+
+
+def set_head_raw_fp32(flag):
+    """False (default; SEGK_HEAD_RAW_FP32=1 turns it on): in bf16 mode the head's convolutions write their
+    pre-normalisation output in bf16, as the feeder's units and PyTorch's autocast do (half the bytes for the three
+    batch-norm passes that read it).  True keeps it in fp32, the accumulator's precision: the normalised values then
+    refer to exactly the numbers the statistics were taken from, and a layer rounds to bf16 once instead of twice."""
+    _state["head_raw_fp32"] = bool(flag)
+
+
+def head_raw_fp32():
+    return _state["head_raw_fp32"]
+
+
+@contextlib.contextmanager
+def head_raw_fp32_as(flag):
+    old = _state["head_raw_fp32"]
+    set_head_raw_fp32(flag)
+    try:
+        yield
+    finally:
+        _state["head_raw_fp32"] = old
 
 
 # ---- debug switches ------------------------------------------------------------------------------------------

@@ -166,6 +166,15 @@ def _dropout_mask(shape, p, device, geom=None):
     return keep.to(torch.uint8), 1.0 / (1.0 - p)
 
 
+def _raw_dtype(x, M):
+    """dtype of a head unit's pre-normalisation output: bf16 for bf16 operands (as the feeder's units and PyTorch's
+    autocast keep it; the statistics still come from the fp32 accumulators), fp32 for fp32 operands (the image-pooling
+    branch has them in either mode) and under config.set_head_raw_fp32."""
+    if x.dtype == torch.bfloat16 and not config.head_raw_fp32():
+        return torch.bfloat16
+    return torch.float32
+
+
 def unit_forward(x, weight, R, dil, geom, spec, gamma, beta, out, relu=True, drop_p=0.0, drop_training=True):
     """conv(x) -> BN -> ReLU -> dropout into `out` (a pixel-major view).  x: [M, >=Ck] view whose padding
     channels are zero.  Returns the record the backward needs."""
@@ -173,9 +182,9 @@ def unit_forward(x, weight, R, dil, geom, spec, gamma, beta, out, relu=True, dro
     M = N * H * W
     Cout, Cin = weight.shape[0], weight.shape[1]
     wp = ops.pack_weight(weight.detach(), x.dtype)
-    # the pre-normalisation output stays fp32 (the accumulator's precision): statistics and the normalised
-    # values then refer to the same numbers, and bf16 mode rounds once per layer instead of twice
-    raw = torch.empty((M, Cout), dtype=torch.float32, device=x.device)
+    # (see _raw_dtype: with config.set_head_raw_fp32 the pre-normalisation output stays in the accumulator's precision,
+    # statistics and normalised values then refer to the same numbers and bf16 mode rounds once per layer, not twice)
+    raw = torch.empty((M, Cout), dtype=_raw_dtype(x, M), device=x.device)
     stats = ops.conv_fwd([(x, wp, R, dil)], N, H, W, Cout, raw, want_stats=spec.training, true_ck=[Cin])
     return unit_finish(x, raw, stats, weight, R, dil, geom, spec, gamma, beta, out, relu, drop_p, drop_training)
 
@@ -457,7 +466,7 @@ class ASPPFunction(torch.autograd.Function):
             keep = wp3 is getattr(mod, "_segk_ladder_pack", None)
             for i, w in enumerate(ws):
                 ops.pack_weight(w.detach(), cd, out=wp3[i], keep=keep)
-            raw3 = torch.empty((M, 3 * P), dtype=torch.float32, device=x.device)
+            raw3 = torch.empty((M, 3 * P), dtype=_raw_dtype(xp, M), device=x.device)
             training = branches[1].bn.training or branches[1].bn.running_mean is None
             stats3 = ops.conv_fwd([(xp, wp3, 3, dils[1])], N, H, W, P, raw3[:, :P], want_stats=training,
                                   true_ck=[Cin], batch=3, dil_step=dils[2] - dils[1], out_batch=P)

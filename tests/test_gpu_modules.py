@@ -284,6 +284,25 @@ def test_decoder_bf16(impl):
     assert_grads_l2("decoder_k21 bf16", got, load_golden("decoder_k21"), "bf16")
 
 
+@pytest.mark.parametrize("which", ["aspp", "decoder"])
+def test_head_bf16_with_fp32_pre_normalisation_output(impl, which):
+    """segk.config.set_head_raw_fp32: the head's convolutions keep their pre-normalisation output in fp32 (one rounding
+    per layer) instead of bf16; the same gates as the default setting."""
+    from segk import config
+    with config.head_raw_fp32_as(True):
+        if which == "aspp":
+            got, want, frac = matched(cases.case_aspp, impl, "cpu", "mobilenet", 16, dtype=torch.bfloat16,
+                                      flips="aspp_mobilenet bf16, fp32 pre-normalisation")
+            gold = load_golden("aspp_mobilenet_os16")
+        else:
+            got, want, frac = matched(cases.case_decoder, impl, "cpu", 21, dtype=torch.bfloat16,
+                                      flips="decoder_k21 bf16, fp32 pre-normalisation")
+            gold = load_golden("decoder_k21")
+    assert_dicts_close(forward_only(got), forward_only(gold), BF)
+    assert_dicts_close(got, want, BF, BF)
+    assert_grads_l2("%s bf16, fp32 pre-normalisation" % which, got, gold, "bf16")
+
+
 # ------------------------------------------------------------ dropout ON ----
 # The masks are inputs: the reference's own draws (recorded in the fixture) for the small cases, the portable
 # generator's for the BASELINE-size head.  Both implementations apply x * keep / (1 - p) on the same masks, forward
