@@ -95,7 +95,7 @@ def test_forward_loss_equals_criterion_of_forward():
         assert float((a - b).norm()) <= 1e-1 * float(a.norm()) + 1e-9, n
 
 
-@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("case", CASES + [(1, 21, 17, 23, 131, 203), (2, 21, 129, 129, 513, 513), (1, 5, 4, 3, 9, 7)])
 def test_upsample_argmax_equals_argmax_of_upsample(case):
     """Bit-exact: the fused kernel blends with the same rounded operations as the kernel that writes the logits."""
     from segk import functional as SF, ops
