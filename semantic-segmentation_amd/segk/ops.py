@@ -625,6 +625,15 @@ def conv_wgrad(x, dout, N, H, W, R, dil, Cout_true, Cin_true, splits=None, like=
     do_ld, Cout = _pm(dout)
     if x.shape[0] != M or dout.shape[0] != M or x.dtype != dout.dtype:
         raise ValueError("wgrad operands disagree: %s %s M=%d" % (tuple(x.shape), tuple(dout.shape), M))
+    # A 1 x 1 gradient is a plain product of the two operands over the pixels, so it can be computed transposed: when
+    # only the INPUT channels fill the ring tile's 256-channel side (512 -> 128, 256 -> 32: the first 1 x 1 of ResNet
+    # layer 2's bottlenecks, the classifier), the operands change places and the fixed-order sum writes the result
+    # back through swapped strides (the same values: every product and every partial sum is the same).
+    swapped = (splits is None and tile == 0 and R == 1 and x.dtype == torch.bfloat16 and Cout % 256 != 0
+               and Cin % 256 == 0 and Cout % 32 == 0 and M >= 4096)
+    if swapped:
+        x, dout, in_ld, do_ld, Cin, Cout = dout, x, do_ld, in_ld, Cout, Cin
+        Cout_true, Cin_true = Cin_true, Cout_true
     if splits is None:   # (an explicit `splits` leaves the tile to the library unless `tile` names it: 128 or 256)
         tile, splits = wgrad_plan(M, Cin, Cout, R, x.dtype)
     slabs = torch.empty((splits, R * R, Cin, Cout), dtype=torch.float32, device=x.device)
@@ -633,13 +642,16 @@ def conv_wgrad(x, dout, N, H, W, R, dil, Cout_true, Cin_true, splits=None, like=
     a.inp, a.in_ld, a.Cin = x.data_ptr(), in_ld, Cin
     a.dout, a.dout_ld, a.Cout = dout.data_ptr(), do_ld, Cout
     a.R, a.dil, a.splits, a.slabs, a.tile = R, dil, splits, slabs.data_ptr(), tile
+    co_t, ci_t = (Cin_true, Cout_true) if swapped else (Cout_true, Cin_true)   # the gradient's own shape
     if like is None:
-        dw = torch.empty((Cout_true, Cin_true, R, R), dtype=torch.float32, device=x.device)
+        dw = torch.empty((co_t, ci_t, R, R), dtype=torch.float32, device=x.device)
     else:
-        if tuple(like.shape) != (Cout_true, Cin_true, R, R):
+        if tuple(like.shape) != (co_t, ci_t, R, R):
             raise ValueError("gradient layout model has shape %s" % (tuple(like.shape),))
         dw = torch.empty_strided(like.shape, like.stride(), dtype=like.dtype, device=x.device)
     s_co, s_ci, s_tap = _weight_strides(dw)
+    if swapped:
+        s_co, s_ci = s_ci, s_co
     # the bracket holds the split-slab kernel AND the fixed-order sum of the slabs: the whole weight-gradient cost
     t0 = TIMER.start() if TIMER is not None else None
     call("segk_conv_wgrad", ctypes.byref(a), _stream())

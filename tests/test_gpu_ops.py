@@ -400,6 +400,40 @@ def test_conv_wgrad_ring_exact_integers(ops, case):
     assert torch.equal(ops.conv_wgrad(xfull, gfull, N, H, W, R, dil, Cout, Cin, splits=parts, tile=128), gw)
 
 
+@pytest.mark.parametrize("case", [(2, 47, 45, 512, 128), (1, 65, 65, 256, 32), (2, 50, 50, 256, 96)])
+@pytest.mark.parametrize("layout", ["contiguous", "channels_last bf16"])
+def test_conv_wgrad_1x1_transposed_on_the_ring_tile(ops, case, layout):
+    """1 x 1 gradients whose OUTPUT channels do not fill the ring tile's 256-channel side but whose input channels do
+    (ResNet layer 2's 512 -> 128, the classifier's 256 -> 21 padded to 32): the operands change places and the sums are
+    written back through swapped strides.  Exact on integers, in both gradient layouts; the older tile agrees."""
+    N, H, W, Cin, Cout = case
+    x = T(gen.integers(9, "rt_x%s" % (case,), (N, Cin, H, W), -3, 4).astype(np.float32))
+    w = torch.zeros((Cout, Cin, 1, 1), device=DEV, requires_grad=True)
+    y = F.conv2d(x, w)
+    gy = T(gen.integers(9, "rt_g%s" % (case,), tuple(y.shape), -2, 3).astype(np.float32))
+    (gw,) = torch.autograd.grad(y, w, gy)
+    _, xfull = to_pm(x, torch.bfloat16)
+    _, gfull = to_pm(gy, torch.bfloat16)
+    like = None
+    if layout != "contiguous":
+        like = torch.empty((Cout, Cin, 1, 1), dtype=torch.bfloat16, device=DEV).contiguous(memory_format=torch.channels_last)
+    seen = []
+    real = ops.call
+
+    def spy(name, *a):
+        seen.append(name)
+        return real(name, *a)
+    from unittest import mock
+    with mock.patch.object(ops, "call", spy):
+        got = ops.conv_wgrad(xfull, gfull, N, H, W, 1, 1, Cout, Cin, like=like)
+    assert "segk_conv_wgrad" in seen
+    assert got.shape == gw.shape and (like is None or (got.dtype == like.dtype and got.stride() == like.stride()))
+    want = gw.to(got.dtype)     # (a bf16 gradient rounds the exact integer sums once)
+    assert torch.equal(got, want)
+    older = ops.conv_wgrad(xfull, gfull, N, H, W, 1, 1, Cout, Cin, splits=4, tile=128, like=like)
+    assert torch.equal(older, want)
+
+
 @pytest.mark.parametrize("case", RING_WGRAD_CASES)
 @pytest.mark.parametrize("groups", [1, 3, 8])
 def test_conv_wgrad_group_exact_integers(ops, case, groups):
