@@ -678,6 +678,18 @@ def _check_labels(target, K, ignore_index):
 
 
 
+def _loss_denominator(pack, size_average, batch_average):
+    """What the summed loss pack[0] is divided by (utils/loss.py:25-35: CrossEntropyLoss(size_average) then `/ n`):
+    the global weight sum pack[1] and / or the global batch pack[2], in as few launches as it takes."""
+    if size_average and batch_average:
+        return pack[1] * pack[2]
+    if size_average:
+        return pack[1]
+    if batch_average:
+        return pack[2]
+    return torch.ones((), dtype=torch.float32, device=pack.device)
+
+
 class CrossEntropyFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logit, target, weight, ignore_index, size_average, batch_average):
@@ -688,11 +700,7 @@ class CrossEntropyFunction(torch.autograd.Function):
         sums, lse = ops.ce_fwd(lg, tg, weight, ignore_index)
         pack = torch.cat([sums, torch.full((1,), float(n), dtype=torch.float32, device=lg.device)])
         parallel.all_reduce_sum_(pack)  # global {sum w*nll, sum w, batch}
-        denom = torch.ones((), dtype=torch.float32, device=lg.device)
-        if size_average:
-            denom = denom * pack[1]
-        if batch_average:
-            denom = denom * pack[2]
+        denom = _loss_denominator(pack, size_average, batch_average)
         ctx.saved = (lg, tg, weight, lse, denom, ignore_index, logit.dtype)
         return pack[0] / denom
 
@@ -722,11 +730,7 @@ class UpsampleCrossEntropyFunction(torch.autograd.Function):
         sums, lse = ops.upsample_ce_fwd(v, N, Hi, Wi, tg, weight, Ho, Wo, ignore_index)
         pack = torch.cat([sums, torch.full((1,), float(N), dtype=torch.float32, device=x.device)])
         parallel.all_reduce_sum_(pack)  # global {sum w*nll, sum w, batch}
-        denom = torch.ones((), dtype=torch.float32, device=x.device)
-        if size_average:
-            denom = denom * pack[1]
-        if batch_average:
-            denom = denom * pack[2]
+        denom = _loss_denominator(pack, size_average, batch_average)
         ctx.saved = (x, v, tg, weight, lse, denom, ignore_index, (N, K, Hi, Wi, Ho, Wo))
         return pack[0] / denom
 
